@@ -1,0 +1,261 @@
+/*
+ * aq3d.h — C ABI of libaq3d.so: the MI355X (gfx950) hot path of quantized CenterPoint inference.
+ *
+ * Every entry point is `extern "C"`, takes raw device addresses (tensor.data_ptr()) and explicit
+ * sizes, enqueues its work on the given hipStream_t (passed as void*), never allocates, never frees,
+ * never synchronises and never calls exit(): it returns 0 on success or a negative aq3d_status.
+ * (The reference's native op for this path aborts the process through CHECK_* macros,
+ * pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:14-26 — this ABI returns codes instead.)
+ *
+ * Dynamic sizes (number of voxels, of active sites, of boxes) live in DEVICE memory (`const int *count`)
+ * next to a host-known capacity, so that a whole frame can be enqueued — or captured into a hipGraph —
+ * without a device→host round trip. Kernels run grid-stride over the capacity and stop at *count.
+ *
+ * Reference interfaces replaced (file:line relative to the reference tree):
+ *   aq3d_voxelize            spconv Point2VoxelCPU3d.point_to_voxel as called from
+ *                            pcdet/datasets/processor/data_processor.py:45-61 (+ MeanVFE, vfe/mean_vfe.py:25-29)
+ *   aq3d_mean_vfe            pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31
+ *   aq3d_hash_build / aq3d_subm_neighbors / aq3d_conv_outputs
+ *                            spconv.pytorch.SubMConv3d / SparseConv3d index generation, call sites
+ *                            pcdet/models/backbones_3d/spconv_backbone.py:12-15,39-46,194-234
+ *   aq3d_absmax_cols / aq3d_quantize_rows
+ *                            pytorch_quantization TensorQuantizer(axis=1) as used in quant/quant.py:21-26,50-52
+ *   aq3d_spconv              spconv gather-GEMM-scatter behind QConvNd.forward, quant/quant.py:36-58,
+ *                            with BN1d/ReLU/residual of spconv_backbone.py:8-27,51-67 fused
+ *   aq3d_scatter_dense       SparseConvTensor.dense() + view, map_to_bev/height_compression.py:19-23
+ *   aq3d_piece_absmax / aq3d_sq_prep / aq3d_conv2d_i8
+ *                            SQConv2d.forward, quant/smoothquant.py:38-99
+ *   aq3d_conv2d_f32          nn.Conv2d / nn.ConvTranspose2d + BatchNorm2d + ReLU of
+ *                            pcdet/models/backbones_2d/base_bev_backbone.py:30-66 and
+ *                            pcdet/models/dense_heads/center_head.py:22-29,75-82 (the layers left in fp32)
+ *   aq3d_center_decode       centernet_utils.decode_bbox_from_heatmap, model_utils/centernet_utils.py:155-241
+ *   aq3d_nms_rotated         iou3d_nms_utils.nms_gpu → iou3d_nms.cpp:137-183 + iou3d_nms_kernel.cu:295-339
+ */
+#ifndef AQ3D_H
+#define AQ3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    AQ3D_OK = 0,
+    AQ3D_ERR_INVALID_ARG = -1,
+    AQ3D_ERR_WORKSPACE = -2,
+    AQ3D_ERR_LAUNCH = -3,
+    AQ3D_ERR_UNSUPPORTED = -4
+} aq3d_status;
+
+/* Human-readable description of the last error on the calling thread ("" if none). */
+const char *aq3d_last_error_string(void);
+/* ABI version, bumped on any signature change. */
+int aq3d_abi_version(void);
+
+/* ---------------------------------------------------------------- voxelization ---------------- */
+
+typedef struct {
+    float range_min[3];       /* x, y, z lower bound of POINT_CLOUD_RANGE */
+    float voxel_size[3];      /* x, y, z VOXEL_SIZE                        */
+    int32_t grid[3];          /* nx, ny, nz                                */
+    int32_t num_features;     /* C: columns kept per point (xyz + used features), 3..8 */
+    int32_t point_stride;     /* floats per input point row (>= C, + 1 if batch column) */
+    int32_t batch_col;        /* 1: column 0 of each row is the batch index (pcdet `points [N,1+C]`) and is skipped */
+    int32_t max_points_per_voxel; /* P (MAX_POINTS_PER_VOXEL), 1..16 */
+    int32_t max_voxels;       /* MAX_NUMBER_OF_VOXELS of one sample; voxels beyond it (first-seen order) are dropped */
+} aq3d_voxel_cfg;
+
+/* Bytes of scratch needed by aq3d_voxelize for up to n_points points. */
+size_t aq3d_voxelize_workspace_bytes(int32_t n_points);
+
+/*
+ * Hard voxelization + mean VFE in one pass.
+ * One call voxelizes ONE sample (as the reference does per sample in its dataset worker); a batch is
+ * built by calling it once per sample with append = 1, which is what collate_batch's concatenation +
+ * batch-index column amounts to (pcdet/datasets/dataset.py:232-244).
+ *   points      f32 [n_points, point_stride] (column 0 skipped when cfg->batch_col)
+ *   batch_index value written to column 0 of the coords rows
+ *   append      0: rows start at 0; 1: rows start at the current *count_io
+ *   coords_out  i32 [cap, 4] rows (b, z, y, x), voxels in first-seen point order
+ *   feats_out   f32 [cap, C] mean over the first P points (in point order) of each voxel
+ *   npts_out    i32 [cap] points kept per voxel (<= P); may be NULL
+ *   count_io    i32 [1] device: total number of rows after the call
+ */
+int aq3d_voxelize(const float *points, int32_t n_points, const aq3d_voxel_cfg *cfg, int32_t batch_index,
+                  int32_t append, int32_t *coords_out, float *feats_out, int32_t *npts_out, int32_t *count_io,
+                  int32_t cap, void *workspace, size_t workspace_bytes, void *stream);
+
+/* voxels f32 [m, P, C], num_points f32 or i32 [m] → feats f32 [m, C] = sum / max(num,1). */
+int aq3d_mean_vfe(const float *voxels, const float *num_points, int32_t m, int32_t P, int32_t C,
+                  float *feats_out, void *stream);
+
+/* ---------------------------------------------------------------- sparse index generation ------ */
+
+/* A coordinate hash table is two arrays owned by the caller: keys i64 [table_size], vals i32 [table_size];
+ * table_size is a power of two, >= 2 * capacity. */
+
+/* Insert coords[0..*count) (rows b,z,y,x) → row index. shape = spatial shape (z, y, x). */
+int aq3d_hash_build(const int32_t *coords, const int32_t *count, int32_t cap, const int32_t shape[3],
+                    int64_t *table_keys, int32_t *table_vals, int32_t table_size, void *stream);
+
+/* Gather table of a submanifold conv: nbr[m][k] = row of the active site at coords[m] + (k - centre),
+ * or -1.  k enumerates (kz, ky, kx) row-major; ksize odd. nbr is i32 [cap, kvol]. */
+int aq3d_subm_neighbors(const int32_t *coords, const int32_t *count, int32_t cap, const int32_t shape[3],
+                        const int32_t ksize[3], const int64_t *table_keys, const int32_t *table_vals,
+                        int32_t table_size, int32_t *nbr_out, void *stream);
+
+size_t aq3d_conv_outputs_workspace_bytes(int32_t cap_in, int32_t kvol, int32_t out_table_size);
+
+/* Active output set + gather table of a strided sparse conv.
+ *   out site o is active iff some active input i = o*stride - pad + k exists (0 <= k < ksize).
+ *   coords_out rows are produced in first-candidate order (input row major, then k).
+ *   nbr_out i32 [cap_out, kvol]: input row feeding output row through kernel offset k, or -1.
+ *   The input hash table (aq3d_hash_build of the inputs) must be valid; the output table is filled here. */
+int aq3d_conv_outputs(const int32_t *coords_in, const int32_t *count_in, int32_t cap_in,
+                      const int32_t shape_in[3], const int32_t ksize[3], const int32_t stride[3],
+                      const int32_t pad[3], const int64_t *in_keys, const int32_t *in_vals, int32_t in_table_size,
+                      int32_t *coords_out, int32_t *count_out, int32_t cap_out, int32_t *nbr_out,
+                      int64_t *out_keys, int32_t *out_vals, int32_t out_table_size,
+                      void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------- sparse conv ----------------- */
+
+/* Per-column abs-max of x f32 [*count, C] → amax f32 [C] (amax must be zeroed by the caller). */
+int aq3d_absmax_cols(const float *x, const int32_t *count, int32_t cap, int32_t C, float *amax, void *stream);
+
+/* TensorQuantizer(axis=1) on rows: scale_c = qmax/amax_c; q = clamp(rint(x*scale_c), -qmax-1, qmax).
+ *   codes_out  i8  [cap, C] integer codes (may be NULL; only for bits <= 8)
+ *   fq_out     f32 [cap, C] fake-quantized values q/scale_c (may be NULL)
+ *   dequant_out f32 [C]     1/scale_c                      (may be NULL)
+ *   per_tensor != 0: one amax = max_c amax_c is used for every column (QuantDescriptor without axis). */
+int aq3d_quantize_rows(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C,
+                       int32_t bits, int32_t per_tensor, int8_t *codes_out, float *fq_out,
+                       float *dequant_out, void *stream);
+
+enum {
+    AQ3D_ACT_F32 = 0,  /* feats_in is f32 [*, Cin] used as is                       */
+    AQ3D_ACT_I8 = 1    /* feats_in is i8 codes [*, Cin]; value = code * act_dequant[c] (scale folded into the gather) */
+};
+enum {
+    AQ3D_W_F32 = 0,    /* weight is f32 [kvol, Cin, Cout]                           */
+    AQ3D_W_I8 = 1      /* weight is i8 codes [kvol, Cin, Cout]; value = code * w_dequant[cout] */
+};
+enum { AQ3D_FLAG_RELU = 1 };
+
+/*
+ * Output-stationary gather-GEMM sparse convolution with fused epilogue:
+ *   acc[m,o]  = sum_k sum_c A[nbr[m][k], c] * W[k][c][o]                  (fp32 accumulate, MFMA)
+ *   y[m,o]    = (acc * w_dequant[o] + bias[o]) * post_scale[o] + post_shift[o]   (bias / post_* may be NULL)
+ *   y        += residual[m,o]                                              (may be NULL)
+ *   y         = max(y, 0) if flags & AQ3D_FLAG_RELU
+ *   absmax_out[o] = max(absmax_out[o], |y[m,o]|) over m                    (may be NULL; caller zeroes it)
+ * Cin in {4..128} padded to a multiple of 4 by the caller (Cin_pad); Cout in {16,32,64,128}.
+ */
+int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant,
+                const void *weight, int32_t w_mode, const float *w_dequant,
+                const float *bias, const float *post_scale, const float *post_shift,
+                const float *residual, const int32_t *nbr, const int32_t *count_out, int32_t cap_out,
+                int32_t cin, int32_t cout, int32_t kvol, int32_t flags,
+                float *feats_out, float *absmax_out, void *stream);
+
+/* ---------------------------------------------------------------- sparse → dense -------------- */
+
+/* out f32 NHWC [B, H, W, C*D] zero-filled then out[b, y, x, c*D + z] = feats[m, c]. shape = (D, H, W). */
+int aq3d_scatter_dense(const float *feats, const int32_t *coords, const int32_t *count, int32_t cap,
+                       int32_t C, const int32_t shape[3], int32_t batch_size, float *out, void *stream);
+
+/* ---------------------------------------------------------------- dense BEV convs ------------- */
+
+/* x f32 NHWC [H, W, C] (one frame) → pieces f32 [16, C]: abs-max of x over each of the 16 classes
+ * (row class) x (col class), class = 0: first, 1: last, 2: interior even, 3: interior odd index.
+ * From these the per-(c,kh,kw) im2col column abs-max of any 3x3 / 1x1 conv with stride 1 or 2 follows exactly.
+ * pieces must be zeroed by the caller. */
+int aq3d_piece_absmax(const float *x, int32_t H, int32_t W, int32_t C, int32_t ldc, float *pieces, void *stream);
+
+typedef struct {
+    int32_t H, W;            /* input height / width                     */
+    int32_t Cin, Cout;
+    int32_t ksize;           /* 1 or 3 (square)                          */
+    int32_t stride;          /* 1 or 2                                   */
+    int32_t pad;             /* zero padding on every side               */
+    int32_t Ho, Wo;          /* output height / width                    */
+    int32_t in_ld;           /* floats between consecutive input pixels  (>= Cin)  */
+    int32_t out_ld;          /* floats between consecutive output pixels (>= Cout) */
+    int32_t out_coff;        /* channel offset inside the output pixel (concat fusion) */
+    int32_t deconv;          /* f32 conv only: ConvTranspose2d with kernel = stride = deconv (1 or 2), ksize must be 1 */
+    int32_t relu;
+} aq3d_conv2d_geom;
+
+/* Bytes of the per-layer, per-frame parameter block written by aq3d_sq_prep and read by aq3d_conv2d_i8. */
+size_t aq3d_sq_param_bytes(int32_t Cin, int32_t Cout, int32_t ksize);
+
+/*
+ * Dynamic SmoothQuant + int8 quantisation parameters of one conv for the current frame.
+ *   pieces     f32 [16, Cin]   from aq3d_piece_absmax of the layer input
+ *   weight     f32 [Cout, K]   K = ksize*ksize*Cin ordered (kh, kw, c)
+ *   w_colmax   f32 [K]         max over Cout of |weight| per column (constant, computed once)
+ *   alpha      SmoothQuant migration strength (scaling_factor); alpha < 0 disables smoothing (s = 1)
+ *   static_amax_x > 0 / static_amax_w != NULL: calibrated amax values instead of dynamic ones
+ *   params     device block of aq3d_sq_param_bytes(): s[K], 1/s[K], wq i8 [Cout,K], out_mul[Cout], sx
+ */
+int aq3d_sq_prep(const float *pieces, const float *weight, const float *w_colmax,
+                 const aq3d_conv2d_geom *g, float alpha, int32_t w_bits, int32_t a_bits,
+                 float static_amax_x, const float *static_amax_w, void *params, void *stream);
+
+/* y = epilogue( int32 GEMM of quantised im2col(x) with quantised weights ) — SQConv2d.forward.
+ *   epilogue: v = acc * out_mul[o] + bias[o]; y = v * post_scale[o] + post_shift[o]; relu. */
+int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_conv2d_geom *g,
+                   const float *bias, const float *post_scale, const float *post_shift,
+                   float *y, void *stream);
+
+/* fp32 conv / transposed conv (MFMA f32), weight f32 [Cout_total, K] with K ordered (kh, kw, c);
+ * for deconv = d the weight rows are ordered (i, j, o): row = (i*d + j)*Cout + o. */
+int aq3d_conv2d_f32(const float *x, const float *weight, const aq3d_conv2d_geom *g,
+                    const float *bias, const float *post_scale, const float *post_shift,
+                    float *y, void *stream);
+
+/* ---------------------------------------------------------------- head decode + NMS ----------- */
+
+typedef struct {
+    int32_t H, W;              /* feature map size                           */
+    int32_t num_classes;       /* classes of this head (<= 16)                */
+    int32_t K;                 /* MAX_OBJ_PER_SAMPLE (<= 512)                 */
+    int32_t has_vel;
+    float feature_map_stride;
+    float voxel_size[2];       /* x, y */
+    float pc_range_min[2];     /* x, y */
+    float post_center_range[6];
+    float score_thresh;        /* strict >; negative disables                */
+    int32_t hm_ld, reg_ld;     /* pixel strides (floats) of the heat map and of the regression maps */
+} aq3d_decode_cfg;
+
+size_t aq3d_center_decode_workspace_bytes(const aq3d_decode_cfg *cfg);
+
+/* Raw head outputs (NHWC f32, pre-sigmoid heat map; dim pre-exp) → candidate boxes sorted by score (desc,
+ * ties by class-major flat index asc) with the range / score mask applied:
+ *   boxes_out f32 [K, 7 or 9], scores_out f32 [K], labels_out i32 [K] (head-local class id), count_out i32 [1]. */
+int aq3d_center_decode(const float *hm, const float *center, const float *center_z, const float *dim,
+                       const float *rot, const float *vel, const aq3d_decode_cfg *cfg,
+                       float *boxes_out, float *scores_out, int32_t *labels_out, int32_t *count_out,
+                       void *workspace, size_t workspace_bytes, void *stream);
+
+size_t aq3d_nms_workspace_bytes(int32_t cap);
+
+/* Rotated BEV-IoU NMS over boxes already sorted by descending score.
+ *   boxes f32 [*count, box_ld] (x,y,z,dx,dy,dz,heading,...); keep_out i32 [cap] indices into boxes in keep order,
+ *   keep_count i32 [1] = min(#kept, post_max). cap <= 4096. */
+int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_t *count, int32_t cap, float thresh,
+                     int32_t post_max, int32_t *keep_out, int32_t *keep_count,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* out rows = in rows gathered by keep (boxes, scores, labels + label_offset) — final pred_dict tensors. */
+int aq3d_gather_dets(const float *boxes, int32_t box_ld, const float *scores, const int32_t *labels,
+                     const int32_t *class_map, const int32_t *keep, const int32_t *keep_count, int32_t cap,
+                     float *boxes_out, float *scores_out, int64_t *labels_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AQ3D_H */

@@ -1,0 +1,360 @@
+// Output-stationary gather-GEMM sparse convolution for gfx950 + the per-channel quantizer around it.
+//
+// What it replaces: QConvNd.forward (quant/quant.py:36-58) = TensorQuantizer(axis=1) on the features,
+// per-out-channel fake-quant of the weight, then spconv's SubMConv3d/SparseConv3d gather-GEMM-scatter, followed by
+// BatchNorm1d + ReLU (+ residual add) of pcdet/models/backbones_3d/spconv_backbone.py:8-27,51-67.
+//
+// Numerics: the reference multiplies fake-quantised fp32 values (integer code / scale) and accumulates in fp32.
+// We reproduce exactly those operands — the activation scale is applied while the gather fills the LDS tile,
+// the weight scale in the epilogue — and accumulate with the f32-input MFMA (v_mfma_f32_16x16x4_f32), which is
+// bit-for-bit an fp32 fma chain. Only the summation order differs from the reference (≈1e-7 relative).
+//
+// Tiling (one 256-thread workgroup = 4 waves owns TM = 16*WR output rows x all COUT columns):
+//   per kernel offset k: rows nbr[m][k] are gathered into As[TM][CIN] (zeros where there is no neighbour),
+//   W_k^T is staged into Bs[COUT][CIN]; every wave then runs CIN/4 MFMA steps per 16x16 output block.
+//   Within a 16-wide K chunk lane group g = lane>>4 supplies k = 4g + s at step s, so that each lane fetches its
+//   A and B operands of four steps with ONE ds_read_b128 each (the k order inside an MFMA is free as long as
+//   A and B agree).  Offsets for which no row of the tile has a neighbour are skipped (wave-uniform).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SpconvArgs {
+    const void *feats_in;
+    const float *act_dequant;
+    const void *weight;
+    const float *w_dequant;
+    const float *bias;
+    const float *post_scale;
+    const float *post_shift;
+    const float *residual;
+    const int *nbr;
+    const int *count_out;
+    float *feats_out;
+    float *absmax_out;
+    int cap_out, cin, kvol, relu;
+};
+
+template <int CIN_PAD, int COUT, int WR, int WC, bool A_I8, bool W_I8>
+__global__ __launch_bounds__(256) void spconv_kernel(SpconvArgs a) {
+    constexpr int TM = 16 * WR;
+    constexpr int NT = COUT / (16 * WC);
+    constexpr int LDA = CIN_PAD + 4;
+    constexpr int C4 = CIN_PAD / 4;
+    static_assert(WR * WC == 4, "4 waves");
+    static_assert(COUT % (16 * WC) == 0, "COUT split");
+    static_assert(CIN_PAD % 16 == 0, "CIN_PAD multiple of 16");
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *As = lds;                                   // [TM][LDA]
+    float *Bs = As + TM * LDA;                         // [COUT][LDA]
+    int *nbr_s = reinterpret_cast<int *>(Bs + COUT * LDA);  // [TM][kvol]
+    float *red = reinterpret_cast<float *>(nbr_s + TM * 27);  // [WR][COUT] abs-max partials
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WR, wc = wave / WR;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int kvol = a.kvol, cin = a.cin;
+
+    int n = *a.count_out;
+    if (n > a.cap_out) n = a.cap_out;
+    const int ntiles = (n + TM - 1) / TM;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * TM;
+        __syncthreads();  // previous tile's epilogue reads of nbr_s/red are done
+        for (int t = tid; t < TM * kvol; t += 256) {
+            int r = row0 + t / kvol;
+            nbr_s[t] = (r < n) ? a.nbr[(size_t)row0 * kvol + t] : -1;
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+
+        for (int k = 0; k < kvol; ++k) {
+            int has = 0;
+            if (tid < TM) has = nbr_s[tid * kvol + k] >= 0;
+            if (!__syncthreads_or(has)) continue;  // barrier: also fences the previous offset's LDS reads
+
+            // ---- gather A rows (activation scale folded in here when the features are int8 codes)
+            if constexpr (A_I8) {
+                // 16 codes (16 B) per thread-item
+                constexpr int C16 = CIN_PAD / 16;
+                for (int t = tid; t < TM * C16; t += 256) {
+                    int r = t / C16, c16 = t - r * C16;
+                    int src = nbr_s[r * kvol + k];
+                    float *dst = As + r * LDA + c16 * 16;
+                    if (src >= 0) {
+                        const int4 q = *reinterpret_cast<const int4 *>(static_cast<const int8_t *>(a.feats_in) +
+                                                                        (size_t)src * cin + c16 * 16);
+                        const int w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            f32x4 v;
+                            const float *dq = a.act_dequant + c16 * 16 + j * 4;
+                            v.x = (float)(int8_t)(w[j] & 0xff) * dq[0];
+                            v.y = (float)(int8_t)((w[j] >> 8) & 0xff) * dq[1];
+                            v.z = (float)(int8_t)((w[j] >> 16) & 0xff) * dq[2];
+                            v.w = (float)(int8_t)((w[j] >> 24) & 0xff) * dq[3];
+                            *reinterpret_cast<f32x4 *>(dst + j * 4) = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4 *>(dst + j * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            } else {
+                const float *fin = static_cast<const float *>(a.feats_in);
+                if ((cin & 3) == 0) {
+                    for (int t = tid; t < TM * C4; t += 256) {
+                        int r = t / C4, c4 = t - r * C4;
+                        int src = nbr_s[r * kvol + k];
+                        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (src >= 0 && c4 * 4 < cin) v = *reinterpret_cast<const f32x4 *>(fin + (size_t)src * cin + c4 * 4);
+                        *reinterpret_cast<f32x4 *>(As + r * LDA + c4 * 4) = v;
+                    }
+                } else {
+                    for (int t = tid; t < TM * CIN_PAD; t += 256) {
+                        int r = t / CIN_PAD, c = t - r * CIN_PAD;
+                        int src = nbr_s[r * kvol + k];
+                        As[r * LDA + c] = (src >= 0 && c < cin) ? fin[(size_t)src * cin + c] : 0.f;
+                    }
+                }
+            }
+            // ---- stage W_k^T: global [kvol][COUT][cin] → Bs[COUT][LDA]
+            if constexpr (W_I8) {
+                constexpr int C16 = CIN_PAD / 16;
+                const int8_t *wk = static_cast<const int8_t *>(a.weight) + (size_t)k * COUT * cin;
+                for (int t = tid; t < COUT * C16; t += 256) {
+                    int o = t / C16, c16 = t - o * C16;
+                    const int4 q = *reinterpret_cast<const int4 *>(wk + (size_t)o * cin + c16 * 16);
+                    const int w[4] = {q.x, q.y, q.z, q.w};
+                    float *dst = Bs + o * LDA + c16 * 16;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v;
+                        v.x = (float)(int8_t)(w[j] & 0xff);
+                        v.y = (float)(int8_t)((w[j] >> 8) & 0xff);
+                        v.z = (float)(int8_t)((w[j] >> 16) & 0xff);
+                        v.w = (float)(int8_t)((w[j] >> 24) & 0xff);
+                        *reinterpret_cast<f32x4 *>(dst + j * 4) = v;
+                    }
+                }
+            } else {
+                const float *wk = static_cast<const float *>(a.weight) + (size_t)k * COUT * cin;
+                if ((cin & 3) == 0) {
+                    for (int t = tid; t < COUT * C4; t += 256) {
+                        int o = t / C4, c4 = t - o * C4;
+                        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                        if (c4 * 4 < cin) v = *reinterpret_cast<const f32x4 *>(wk + (size_t)o * cin + c4 * 4);
+                        *reinterpret_cast<f32x4 *>(Bs + o * LDA + c4 * 4) = v;
+                    }
+                } else {
+                    for (int t = tid; t < COUT * CIN_PAD; t += 256) {
+                        int o = t / CIN_PAD, c = t - o * CIN_PAD;
+                        Bs[o * LDA + c] = (c < cin) ? wk[(size_t)o * cin + c] : 0.f;
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- MFMA: 16 rows x (NT*16) cols per wave, K = CIN_PAD
+            const float *arow = As + (wr * 16 + l15) * LDA + 4 * g;
+            const float *brow = Bs + ((wc * NT) * 16 + l15) * LDA + 4 * g;
+#pragma unroll 2
+            for (int kc = 0; kc < CIN_PAD; kc += 16) {
+                const f32x4 af = *reinterpret_cast<const f32x4 *>(arow + kc);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x4 bf = *reinterpret_cast<const f32x4 *>(brow + nt * 16 * LDA + kc);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.x, bf.x, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.y, bf.y, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.z, bf.z, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af.w, bf.w, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue. D layout: col = lane&15 (out channel), row = 4*g + reg (tile row).
+        float cmax[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int o = (wc * NT + nt) * 16 + l15;
+            const float wdq = a.w_dequant ? a.w_dequant[o] : 1.f;
+            const float b = a.bias ? a.bias[o] : 0.f;
+            const float ps = a.post_scale ? a.post_scale[o] : 1.f;
+            const float pt = a.post_shift ? a.post_shift[o] : 0.f;
+            float mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = row0 + wr * 16 + 4 * g + r;
+                if (m < n) {
+                    float v = acc[nt][r];
+                    if (a.w_dequant) v = v * wdq;
+                    if (a.bias) v = v + b;
+                    if (a.post_scale) v = v * ps + pt;
+                    if (a.residual) v += a.residual[(size_t)m * COUT + o];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.feats_out[(size_t)m * COUT + o] = v;
+                    mx = fmaxf(mx, fabsf(v));
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            cmax[nt] = mx;
+        }
+        if (a.absmax_out) {
+            if (g == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) red[wr * COUT + (wc * NT + nt) * 16 + l15] = cmax[nt];
+            }
+            __syncthreads();
+            for (int o = tid; o < COUT; o += 256) {
+                float mx = red[o];
+#pragma unroll
+                for (int w = 1; w < WR; ++w) mx = fmaxf(mx, red[w * COUT + o]);
+                // monotone: a stale read only costs an extra atomic
+                if (mx > a.absmax_out[o]) aq3d_atomic_max_pos(&a.absmax_out[o], mx);
+            }
+        }
+    }
+}
+
+template <int CIN_PAD, int COUT, int WR, int WC>
+static int spconv_launch_modes(const SpconvArgs &a, int act_mode, int w_mode, hipStream_t stream) {
+    constexpr int TM = 16 * WR;
+    constexpr size_t lds = (size_t)(TM + COUT) * (CIN_PAD + 4) * 4 + (size_t)TM * 27 * 4 + (size_t)WR * COUT * 4;
+    const int tiles = aq3d_div_up(a.cap_out, TM);
+    const int grid = tiles < 2048 ? (tiles < 1 ? 1 : tiles) : 2048;
+#define AQ3D_SPCONV_GO(AI8, WI8)                                                                               \
+    do {                                                                                                       \
+        auto kern = spconv_kernel<CIN_PAD, COUT, WR, WC, AI8, WI8>;                                            \
+        if (lds > 64 * 1024)                                                                                   \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);                                        \
+    } while (0)
+    if (act_mode == AQ3D_ACT_I8 && w_mode == AQ3D_W_I8) AQ3D_SPCONV_GO(true, true);
+    else if (act_mode == AQ3D_ACT_I8) AQ3D_SPCONV_GO(true, false);
+    else if (w_mode == AQ3D_W_I8) AQ3D_SPCONV_GO(false, true);
+    else AQ3D_SPCONV_GO(false, false);
+#undef AQ3D_SPCONV_GO
+    AQ3D_CHECK_LAUNCH("aq3d_spconv");
+    return AQ3D_OK;
+}
+
+extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
+                           int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
+                           const float *post_shift, const float *residual, const int32_t *nbr,
+                           const int32_t *count_out, int32_t cap_out, int32_t cin, int32_t cout, int32_t kvol,
+                           int32_t flags, float *feats_out, float *absmax_out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(feats_in && weight && nbr && count_out && feats_out, "aq3d_spconv: null argument");
+    AQ3D_REQUIRE(cap_out > 0 && kvol >= 1 && kvol <= 27, "aq3d_spconv: cap_out=%d kvol=%d", cap_out, kvol);
+    AQ3D_REQUIRE(cin >= 1 && cin <= 128, "aq3d_spconv: cin=%d not in 1..128", cin);
+    AQ3D_REQUIRE(act_mode != AQ3D_ACT_I8 || ((cin % 16) == 0 && act_dequant), "aq3d_spconv: int8 activations need cin%%16==0 and act_dequant");
+    AQ3D_REQUIRE(w_mode != AQ3D_W_I8 || ((cin % 16) == 0 && w_dequant), "aq3d_spconv: int8 weights need cin%%16==0 and w_dequant");
+    AQ3D_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "aq3d_spconv: post_scale/post_shift must come together");
+    SpconvArgs a;
+    a.feats_in = feats_in; a.act_dequant = act_dequant; a.weight = weight; a.w_dequant = w_dequant;
+    a.bias = bias; a.post_scale = post_scale; a.post_shift = post_shift; a.residual = residual;
+    a.nbr = nbr; a.count_out = count_out; a.feats_out = feats_out; a.absmax_out = absmax_out;
+    a.cap_out = cap_out; a.cin = cin; a.kvol = kvol; a.relu = (flags & AQ3D_FLAG_RELU) ? 1 : 0;
+    const int cin_pad = (cin + 15) / 16 * 16;
+#define AQ3D_SPCONV_CASE(CP, CO, WR_, WC_) \
+    if (cin_pad == CP && cout == CO) return spconv_launch_modes<CP, CO, WR_, WC_>(a, act_mode, w_mode, stream);
+    AQ3D_SPCONV_CASE(16, 16, 4, 1)
+    AQ3D_SPCONV_CASE(16, 32, 2, 2)
+    AQ3D_SPCONV_CASE(32, 32, 2, 2)
+    AQ3D_SPCONV_CASE(32, 64, 2, 2)
+    AQ3D_SPCONV_CASE(64, 64, 2, 2)
+    AQ3D_SPCONV_CASE(64, 128, 2, 2)
+    AQ3D_SPCONV_CASE(128, 128, 2, 2)
+#undef AQ3D_SPCONV_CASE
+    aq3d_set_error("aq3d_spconv: unsupported channel pair cin=%d (pad %d) cout=%d", cin, cin_pad, cout);
+    return AQ3D_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------- per-column abs-max + quantizer
+__global__ __launch_bounds__(256) void absmax_cols_kernel(const float *__restrict__ x, const int *count, int cap, int C,
+                                                          float *amax) {
+    __shared__ float red[256];
+    int n = *count;
+    if (n > cap) n = cap;
+    // thread t owns column (t % C) of rows t / C, stepping by 256 / C rows (C divides 256 or C <= 256)
+    const int rows_per_pass = 256 / C;
+    const int c = threadIdx.x % C, r0 = threadIdx.x / C;
+    float mx = 0.f;
+    if (r0 < rows_per_pass)
+        for (int r = blockIdx.x * rows_per_pass + r0; r < n; r += gridDim.x * rows_per_pass)
+            mx = fmaxf(mx, fabsf(x[(size_t)r * C + c]));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    if (threadIdx.x < C) {
+        for (int j = 1; j < rows_per_pass; ++j) mx = fmaxf(mx, red[j * C + threadIdx.x]);
+        if (mx > amax[threadIdx.x]) aq3d_atomic_max_pos(&amax[threadIdx.x], mx);
+    }
+}
+
+extern "C" int aq3d_absmax_cols(const float *x, const int32_t *count, int32_t cap, int32_t C, float *amax,
+                                void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(x && count && amax, "aq3d_absmax_cols: null argument");
+    AQ3D_REQUIRE(C >= 1 && C <= 256, "aq3d_absmax_cols: C=%d not in 1..256", C);
+    const int rows_per_pass = 256 / C;
+    hipLaunchKernelGGL(absmax_cols_kernel, dim3(aq3d_grid(aq3d_div_up(cap, rows_per_pass), 1, 1024)), dim3(256), 0, stream,
+                       x, count, cap, C, amax);
+    AQ3D_CHECK_LAUNCH("aq3d_absmax_cols");
+    return AQ3D_OK;
+}
+
+// TensorQuantizer restatement: scale = qmax / amax (0 where amax <= 2^-24), q = clamp(rint(x*scale), -qmax-1, qmax),
+// fake-quant value = q / scale (scale := 1 where amax <= 2^-24).  rintf = round-half-to-even = torch.round.
+__global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restrict__ x, const float *__restrict__ amax,
+                                                            const int *count, int cap, int C, float qmax,
+                                                            int per_tensor, int8_t *__restrict__ codes,
+                                                            float *__restrict__ fq, float *__restrict__ dequant) {
+    __shared__ float s_scale[256];
+    __shared__ float s_div[256];
+    int n = *count;
+    if (n > cap) n = cap;
+    if (threadIdx.x < C) {
+        float am = amax[threadIdx.x];
+        if (per_tensor) {
+            am = 0.f;
+            for (int c = 0; c < C; ++c) am = fmaxf(am, amax[c]);
+        }
+        const float eps = 1.0f / (float)(1 << 24);
+        float scale = __fdiv_rn(qmax, am);
+        float dv = scale;
+        if (am <= eps) { scale = 0.f; dv = 1.f; }
+        s_scale[threadIdx.x] = scale;
+        s_div[threadIdx.x] = dv;
+        if (dequant && blockIdx.x == 0) dequant[threadIdx.x] = __fdiv_rn(1.0f, dv);
+    }
+    __syncthreads();
+    const long long total = (long long)n * C;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        int c = (int)(t % C);
+        float q = rintf(__fmul_rn(x[t], s_scale[c]));
+        q = fminf(fmaxf(q, -qmax - 1.f), qmax);
+        if (codes) codes[t] = (int8_t)(int)q;
+        if (fq) fq[t] = __fdiv_rn(q, s_div[c]);
+    }
+}
+
+extern "C" int aq3d_quantize_rows(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C,
+                                  int32_t bits, int32_t per_tensor, int8_t *codes_out, float *fq_out,
+                                  float *dequant_out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(x && amax && count, "aq3d_quantize_rows: null argument");
+    AQ3D_REQUIRE(C >= 1 && C <= 256, "aq3d_quantize_rows: C=%d not in 1..256", C);
+    AQ3D_REQUIRE(bits >= 2 && bits <= 16, "aq3d_quantize_rows: bits=%d", bits);
+    AQ3D_REQUIRE(!(codes_out && bits > 8), "aq3d_quantize_rows: int8 codes need bits <= 8");
+    const float qmax = (float)((1 << (bits - 1)) - 1);
+    hipLaunchKernelGGL(quantize_rows_kernel, dim3(aq3d_grid((int64_t)cap * C, 256)), dim3(256), 0, stream, x, amax, count,
+                       cap, C, qmax, per_tensor, codes_out, fq_out, dequant_out);
+    AQ3D_CHECK_LAUNCH("aq3d_quantize_rows");
+    return AQ3D_OK;
+}

@@ -1,0 +1,99 @@
+"""ctypes binding of libaq3d.so (the C ABI declared in include/aq3d.h).
+
+The product path has NO fallback: if the library is missing or a symbol is absent this module raises.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
+
+ABI_VERSION = 1
+
+
+class Aq3dError(RuntimeError):
+    pass
+
+
+class VoxelCfg(Structure):
+    _fields_ = [("range_min", c_float * 3), ("voxel_size", c_float * 3), ("grid", c_int32 * 3),
+                ("num_features", c_int32), ("point_stride", c_int32), ("batch_col", c_int32),
+                ("max_points_per_voxel", c_int32), ("max_voxels", c_int32)]
+
+
+class Conv2dGeom(Structure):
+    _fields_ = [("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("Cout", c_int32), ("ksize", c_int32),
+                ("stride", c_int32), ("pad", c_int32), ("Ho", c_int32), ("Wo", c_int32), ("in_ld", c_int32),
+                ("out_ld", c_int32), ("out_coff", c_int32), ("deconv", c_int32), ("relu", c_int32)]
+
+
+class DecodeCfg(Structure):
+    _fields_ = [("H", c_int32), ("W", c_int32), ("num_classes", c_int32), ("K", c_int32), ("has_vel", c_int32),
+                ("feature_map_stride", c_float), ("voxel_size", c_float * 2), ("pc_range_min", c_float * 2),
+                ("post_center_range", c_float * 6), ("score_thresh", c_float), ("hm_ld", c_int32),
+                ("reg_ld", c_int32)]
+
+
+I3 = c_int32 * 3
+P = c_void_p
+
+# name -> (restype, argtypes); mirrors include/aq3d.h one to one.
+SIGNATURES = {
+    "aq3d_last_error_string": (c_char_p, []),
+    "aq3d_abi_version": (c_int32, []),
+    "aq3d_voxelize_workspace_bytes": (c_size_t, [c_int32]),
+    "aq3d_voxelize": (c_int32, [P, c_int32, POINTER(VoxelCfg), c_int32, c_int32, P, P, P, P, c_int32, P, c_size_t, P]),
+    "aq3d_mean_vfe": (c_int32, [P, P, c_int32, c_int32, c_int32, P, P]),
+    "aq3d_hash_build": (c_int32, [P, P, c_int32, I3, P, P, c_int32, P]),
+    "aq3d_subm_neighbors": (c_int32, [P, P, c_int32, I3, I3, P, P, c_int32, P, P]),
+    "aq3d_conv_outputs_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "aq3d_conv_outputs": (c_int32, [P, P, c_int32, I3, I3, I3, I3, P, P, c_int32, P, P, c_int32, P, P, P, c_int32,
+                                    P, c_size_t, P]),
+    "aq3d_absmax_cols": (c_int32, [P, P, c_int32, c_int32, P, P]),
+    "aq3d_quantize_rows": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
+    "aq3d_spconv": (c_int32, [P, c_int32, P, P, c_int32, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32,
+                              c_int32, P, P, P]),
+    "aq3d_scatter_dense": (c_int32, [P, P, P, c_int32, c_int32, I3, c_int32, P, P]),
+    "aq3d_piece_absmax": (c_int32, [P, c_int32, c_int32, c_int32, c_int32, P, P]),
+    "aq3d_sq_param_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "aq3d_sq_prep": (c_int32, [P, P, P, POINTER(Conv2dGeom), c_float, c_int32, c_int32, c_float, P, P, P]),
+    "aq3d_conv2d_i8": (c_int32, [P, P, POINTER(Conv2dGeom), P, P, P, P, P]),
+    "aq3d_conv2d_f32": (c_int32, [P, P, POINTER(Conv2dGeom), P, P, P, P, P]),
+    "aq3d_center_decode_workspace_bytes": (c_size_t, [POINTER(DecodeCfg)]),
+    "aq3d_center_decode": (c_int32, [P, P, P, P, P, P, POINTER(DecodeCfg), P, P, P, P, P, c_size_t, P]),
+    "aq3d_nms_workspace_bytes": (c_size_t, [c_int32]),
+    "aq3d_nms_rotated": (c_int32, [P, c_int32, P, c_int32, c_float, c_int32, P, P, P, c_size_t, P]),
+    "aq3d_gather_dets": (c_int32, [P, c_int32, P, P, P, P, P, c_int32, P, P, P, P]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """Load libaq3d.so and bind every symbol of include/aq3d.h. Raises if anything is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.isfile(path):
+        raise Aq3dError("libaq3d.so not found at %s — build it with `python __graft_entry__.py` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise Aq3dError("libaq3d.so at %s does not export %s" % (path, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.aq3d_abi_version() != ABI_VERSION:
+        raise Aq3dError("libaq3d.so ABI %d != binding ABI %d" % (lib.aq3d_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().aq3d_last_error_string()
+        raise Aq3dError("%s failed (status %d): %s" % (what or "aq3d call", rc, msg.decode() if msg else ""))

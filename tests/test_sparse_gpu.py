@@ -1,0 +1,179 @@
+"""GPU parity: voxelizer, rulebook and sparse conv (through the C ABI) vs the CPU oracle.
+
+Bars: voxel coordinates / counts / gather tables bit-exact; voxel mean features bit-exact (same fp32 op order);
+sparse conv within 2e-5 relative to the row scale (fp32, summation order differs).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import quantizer as OQ
+from oracle import sparse as OS
+from oracle import voxel as OV
+
+pytestmark = pytest.mark.gpu
+
+RANGE = [-8.0, -8.0, -2.0, 8.0, 8.0, 4.0]
+VSIZE = [0.1, 0.1, 0.15]
+
+
+def _cloud(n, seed, dup=0.3):
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform([-9, -9, -2.5, 0, 0], [9, 9, 4.5, 1, 1.5], size=(n, 5)).astype(np.float32)
+    # clustered duplicates so that many voxels hold more than P points
+    k = int(n * dup)
+    src = rng.integers(0, n, size=k)
+    pts[rng.integers(0, n, size=k)] = pts[src] + rng.normal(0, 0.01, size=(k, 5)).astype(np.float32)
+    # exact cell faces / range ends
+    pts[:50, 0] = np.float32(-8.0) + np.arange(50, dtype=np.float32) * np.float32(0.1)
+    pts[50:60, 0] = np.float32(8.0)
+    pts[60:70, 2] = np.float32(-2.0)
+    pts[70:75, 1] = np.float32(-0.0)
+    return pts
+
+
+def _voxelize_gpu(pts, P, max_voxels, cap, dev):
+    from amdq3d import ops
+    grid = OV.grid_size_of(RANGE, VSIZE)
+    cfg = ops.make_voxel_cfg(RANGE, VSIZE, grid, 5, 5, False, P, max_voxels)
+    coords, feats, npts, count = ops.voxelize(torch.from_numpy(pts).to(dev), cfg, cap)
+    m = int(count.item())
+    return coords[:m].cpu().numpy(), feats[:m].cpu().numpy(), npts[:m].cpu().numpy(), m
+
+
+@pytest.mark.parametrize("n,P,max_voxels", [(20000, 5, 150000), (3000, 2, 150000), (20000, 5, 700), (1, 5, 10)])
+def test_voxelize_bit_exact(dev, n, P, max_voxels):
+    pts = _cloud(max(n, 100), seed=n)[:n]
+    f_ref, c_ref, n_ref = OV.voxelize_mean(pts, RANGE, VSIZE, P, max_voxels)
+    c, f, npts, m = _voxelize_gpu(pts, P, max_voxels, cap=max(len(c_ref) + 64, 128), dev=dev)
+    assert m == len(c_ref)
+    np.testing.assert_array_equal(c, c_ref)           # same rows in the same (first-seen) order
+    np.testing.assert_array_equal(npts, n_ref)
+    np.testing.assert_array_equal(f.view(np.uint32), f_ref.view(np.uint32))   # bit-exact means
+
+
+def test_voxelize_empty_and_append(dev):
+    from amdq3d import ops
+    grid = OV.grid_size_of(RANGE, VSIZE)
+    cfg = ops.make_voxel_cfg(RANGE, VSIZE, grid, 5, 5, False, 5, 1000)
+    empty = torch.zeros((0, 5), device=dev)
+    _, _, _, count = ops.voxelize(empty, cfg, 16)
+    assert int(count.item()) == 0
+    far = torch.full((10, 5), 100.0, device=dev)      # everything out of range
+    _, _, _, count = ops.voxelize(far, cfg, 16)
+    assert int(count.item()) == 0
+    a, b = _cloud(2000, 1), _cloud(1500, 2)
+    fa, ca, _ = OV.voxelize_mean(a, RANGE, VSIZE, 5, 1000, batch_index=0)
+    fb, cb, _ = OV.voxelize_mean(b, RANGE, VSIZE, 5, 1000, batch_index=1)
+    out = ops.voxelize(torch.from_numpy(a).to(dev), cfg, 4096, batch_index=0)
+    out = ops.voxelize(torch.from_numpy(b).to(dev), cfg, 4096, batch_index=1, append=True, out=out)
+    m = int(out[3].item())
+    assert m == len(ca) + len(cb)
+    np.testing.assert_array_equal(out[0][:m].cpu().numpy(), np.concatenate([ca, cb]))
+    np.testing.assert_array_equal(out[1][:m].cpu().numpy(), np.concatenate([fa, fb]))
+
+
+def _sparse_input(dev, m_pts=6000, seed=3, batch=2):
+    shape = [41, 160, 160]
+    rng = np.random.default_rng(seed)
+    idx = np.stack([rng.integers(0, batch, m_pts), rng.integers(0, 12, m_pts), rng.integers(0, 60, m_pts),
+                    rng.integers(0, 60, m_pts)], axis=1).astype(np.int32)
+    idx = np.unique(idx, axis=0)
+    rng.shuffle(idx)
+    return idx, shape
+
+
+def test_subm_neighbors_exact(dev):
+    from amdq3d import ops
+    idx, shape = _sparse_input(dev)
+    cap = len(idx) + 100
+    coords = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    coords[:len(idx)] = torch.from_numpy(idx).to(dev)
+    count = torch.tensor([len(idx)], dtype=torch.int32, device=dev)
+    table = ops.hash_build(coords, count, shape)
+    nbr = ops.subm_neighbors(coords, count, shape, (3, 3, 3), table)[:len(idx)].cpu().numpy()
+    np.testing.assert_array_equal(nbr, OS.subm_neighbors(idx, shape, (3, 3, 3)))
+
+
+@pytest.mark.parametrize("ksize,stride,pad", [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
+                                              ((3, 1, 1), (2, 1, 1), (0, 0, 0))])
+def test_conv_outputs_exact(dev, ksize, stride, pad):
+    from amdq3d import ops
+    idx, shape = _sparse_input(dev, seed=5)
+    cap = len(idx) + 17
+    coords = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    coords[:len(idx)] = torch.from_numpy(idx).to(dev)
+    count = torch.tensor([len(idx)], dtype=torch.int32, device=dev)
+    table = ops.hash_build(coords, count, shape)
+    o_ref, nbr_ref, oshape = OS.conv_outputs(idx, shape, ksize, stride, pad)
+    co, cnt, nbr, _ = ops.conv_outputs(coords, count, shape, ksize, stride, pad, table, cap_out=len(o_ref) + 33)
+    m = int(cnt.item())
+    assert m == len(o_ref)
+    co, nbr = co[:m].cpu().numpy(), nbr[:m].cpu().numpy()
+    key = OS._key(co, oshape)
+    assert len(np.unique(key)) == m
+    order = np.argsort(key)
+    np.testing.assert_array_equal(co[order], o_ref)     # same active set
+    np.testing.assert_array_equal(nbr[order], nbr_ref)  # same gather table, row for row
+
+
+@pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)])
+def test_spconv_f32(dev, cin, cout):
+    from amdq3d import ops
+    idx, shape = _sparse_input(dev, m_pts=3000, seed=cin + cout, batch=1)
+    m = len(idx)
+    rng = np.random.default_rng(cin * 7 + cout)
+    feats = rng.normal(0, 1, (m, cin)).astype(np.float32)
+    w = (rng.normal(0, 1, (cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    bias = rng.normal(0, 0.1, cout).astype(np.float32)
+    ps = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    pt = rng.normal(0, 0.1, cout).astype(np.float32)
+    res = rng.normal(0, 1, (m, cout)).astype(np.float32)
+    nbr_ref = OS.subm_neighbors(idx, shape)
+    ref = OS.gather_conv(feats, w, nbr_ref, bias)
+    ref = np.maximum(ref * ps + pt + res, 0)
+    cap = m + 37
+    nbr = torch.full((cap, 27), -1, dtype=torch.int32, device=dev)
+    nbr[:m] = torch.from_numpy(nbr_ref).to(dev)
+    count = torch.tensor([m], dtype=torch.int32, device=dev)
+    fin = torch.zeros((cap, cin), device=dev); fin[:m] = torch.from_numpy(feats).to(dev)
+    rs = torch.zeros((cap, cout), device=dev); rs[:m] = torch.from_numpy(res).to(dev)
+    wk = torch.from_numpy(np.ascontiguousarray(w.reshape(cout, 27, cin).transpose(1, 0, 2))).to(dev)
+    amax = torch.zeros((cout,), device=dev)
+    y = ops.spconv(fin, wk, nbr, count, cout, bias=torch.from_numpy(bias).to(dev), post_scale=torch.from_numpy(ps).to(dev),
+                   post_shift=torch.from_numpy(pt).to(dev), residual=rs, relu=True, absmax_out=amax)[:m].cpu().numpy()
+    tol = 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(y - ref).max() <= tol
+    np.testing.assert_allclose(amax.cpu().numpy(), np.abs(y).max(axis=0), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (128, 128)])
+def test_spconv_int8_codes(dev, cin, cout):
+    """QConvNd semantics: per-column activation codes (scale folded into the gather) x per-out-channel weight codes."""
+    from amdq3d import ops
+    idx, shape = _sparse_input(dev, m_pts=2500, seed=cin, batch=1)
+    m = len(idx)
+    rng = np.random.default_rng(cout)
+    feats = np.maximum(rng.normal(0, 1, (m, cin)), 0).astype(np.float32) * rng.uniform(0.1, 4, cin).astype(np.float32)
+    w = (rng.normal(0, 1, (cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    wq, wcodes, wdiv = OS.qconv_weight(w, 8)
+    aq, amax_ref = OS.qconv_act(feats, 8, cw=True)
+    nbr_ref = OS.subm_neighbors(idx, shape)
+    ref = OS.gather_conv(aq, wq, nbr_ref)
+    cap = m + 5
+    nbr = torch.full((cap, 27), -1, dtype=torch.int32, device=dev); nbr[:m] = torch.from_numpy(nbr_ref).to(dev)
+    count = torch.tensor([m], dtype=torch.int32, device=dev)
+    fin = torch.zeros((cap, cin), device=dev); fin[:m] = torch.from_numpy(feats).to(dev)
+    amax = ops.absmax_cols(fin, count)
+    np.testing.assert_array_equal(amax.cpu().numpy(), amax_ref.reshape(-1))
+    codes, fq, dq = ops.quantize_rows(fin, amax, count, bits=8, want_codes=True, want_fq=True)
+    np.testing.assert_array_equal(fq[:m].cpu().numpy().view(np.uint32), aq.view(np.uint32))   # bit-exact fake quant
+    wk_codes = torch.from_numpy(np.ascontiguousarray(wcodes.reshape(cout, 27, cin).transpose(1, 0, 2)).astype(np.int8)).to(dev)
+    wdq = torch.from_numpy((np.float32(1.0) / wdiv).astype(np.float32)).to(dev)
+    y = ops.spconv(codes, wk_codes, nbr, count, cout, act_dequant=dq, w_dequant=wdq)[:m].cpu().numpy()
+    tol = 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(y - ref).max() <= tol
+    # fp32 fake-quant operands through the same kernel
+    wk_fq = torch.from_numpy(np.ascontiguousarray(wq.reshape(cout, 27, cin).transpose(1, 0, 2))).to(dev)
+    y2 = ops.spconv(fq, wk_fq, nbr, count, cout)[:m].cpu().numpy()
+    assert np.abs(y2 - ref).max() <= tol
