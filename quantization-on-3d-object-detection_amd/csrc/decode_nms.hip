@@ -1,0 +1,444 @@
+// CenterHead decode (top-K over the heat map, box assembly, range/score mask) and rotated BEV NMS, all on device.
+//
+// Reference semantics:
+//   decode  — pcdet/models/model_utils/centernet_utils.py:155-241 (_topk: per-class top-K over H*W, then top-K over
+//             classes*K; gather; atan2; x = (xs + dx) * stride * voxel + range_min; range + score mask),
+//             called from pcdet/models/dense_heads/center_head.py:297-330 (sigmoid on hm, exp on dim).
+//   NMS     — pcdet/models/model_utils/model_nms_utils.py:6-25 → pcdet/ops/iou3d_nms/iou3d_nms_utils.py:120-135 →
+//             pcdet/ops/iou3d_nms/src/iou3d_nms.cpp:137-183 (bitmask + greedy sweep) with the rotated-rectangle IoU of
+//             pcdet/ops/iou3d_nms/src/iou3d_nms_kernel.cu:35-234 (== iou3d_cpu.cpp:59-229).
+// Differences by design: the reference copies the N x N/64 bitmask to the host and sweeps it on the CPU
+// (one blocking D2H per head per frame); here one wave sweeps it on device, 64 boxes per step. torch.topk's order
+// among equal scores is unspecified; we fix it to (score desc, flat index asc) and the oracle does the same.
+#include "common.h"
+
+typedef unsigned long long u64;
+
+// ------------------------------------------------------------------ block-wide helpers (1024 threads)
+__device__ __forceinline__ int block_scan_excl_1024(int v, int *sh, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) sh[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+    for (int w = 0; w < 16; ++w) {
+        int s = sh[w];
+        if (w < wave) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// in-LDS bitonic sort, descending, n = power of two, any block size
+__device__ __forceinline__ void bitonic_sort_desc(u64 *keys, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    u64 a = keys[i], b = keys[ixj];
+                    bool desc = (i & k) == 0;
+                    if (desc ? (a < b) : (a > b)) {
+                        keys[i] = b;
+                        keys[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_dev(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
+
+// ------------------------------------------------------------------ stage 1: per-class top-K (radix select + sort)
+// grid = num_classes, block = 1024. Writes K composite keys (score bits << 32 | ~index) per class, sorted descending;
+// slots beyond the number of pixels hold 0.
+__global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__restrict__ hm, int hm_ld, int L, int K,
+                                                              int Kpad, u64 *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *sel = reinterpret_cast<u64 *>(smem_raw);          // [Kpad]
+    int *hist = reinterpret_cast<int *>(sel + Kpad);       // [256]
+    int *sh = hist + 256;                                  // [16]
+    __shared__ unsigned int s_prefix;
+    __shared__ int s_remaining, s_fill;
+    const int cls = blockIdx.x;
+    const float *col = hm + cls;
+    const int Keff = K < L ? K : L;
+
+    // 4-pass MSB radix select on the 32-bit score keys: find T = Keff-th largest key
+    if (threadIdx.x == 0) { s_prefix = 0u; s_remaining = Keff; }
+    __syncthreads();
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        const unsigned int prefix = s_prefix;
+        const unsigned int pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+        for (int i = threadIdx.x; i < L; i += blockDim.x) {
+            unsigned int key = __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int rem = s_remaining, b = 255;
+            for (; b > 0; --b) {
+                if (hist[b] >= rem) break;
+                rem -= hist[b];
+            }
+            s_prefix = prefix | ((unsigned int)b << shift);
+            s_remaining = rem;  // how many keys equal to the final prefix are still needed
+        }
+        __syncthreads();
+    }
+    const unsigned int T = s_prefix;
+    const int need_ties = s_remaining;
+    for (int i = threadIdx.x; i < Kpad; i += blockDim.x) sel[i] = 0ull;
+    if (threadIdx.x == 0) s_fill = 0;
+    __syncthreads();
+    // keys > T in any order (sorted afterwards)
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        unsigned int key = __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
+        if (key > T) {
+            int pos = atomicAdd(&s_fill, 1);
+            sel[pos] = ((u64)key << 32) | (u64)(0xffffffffu - (unsigned int)i);
+        }
+    }
+    __syncthreads();
+    // keys == T in ascending index order until need_ties are taken (ordered compaction, 1024 pixels per round)
+    int taken = 0;
+    const int gt = s_fill;
+    for (int base = 0; base < L && taken < need_ties; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        int f = 0;
+        if (i < L) f = (__float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld])) == T) ? 1 : 0;
+        int tot;
+        int pos = block_scan_excl_1024(f, sh, &tot);
+        if (f && taken + pos < need_ties) sel[gt + taken + pos] = ((u64)T << 32) | (u64)(0xffffffffu - (unsigned int)i);
+        taken += tot;
+    }
+    __syncthreads();
+    bitonic_sort_desc(sel, Kpad);
+    for (int i = threadIdx.x; i < K; i += blockDim.x) out[(size_t)cls * K + i] = (i < Keff) ? sel[i] : 0ull;
+}
+
+// ------------------------------------------------------------------ stage 2: top-K over classes*K, decode, mask
+struct DecodeParams {
+    aq3d_decode_cfg c;
+    const float *center, *center_z, *dim, *rot, *vel;
+};
+
+__global__ __launch_bounds__(1024) void decode_kernel(const u64 *__restrict__ cand, int ncand, int Npad, DecodeParams q,
+                                                      float *__restrict__ boxes_out, float *__restrict__ scores_out,
+                                                      int *__restrict__ labels_out, int *__restrict__ count_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *keys = reinterpret_cast<u64 *>(smem_raw);  // [Npad] : score bits << 32 | ~position (position = class*K + rank)
+    __shared__ int sh[16];
+    const int K = q.c.K;
+    for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
+        u64 v = 0ull;
+        if (i < ncand) {
+            u64 cv = cand[i];
+            v = (cv & 0xffffffff00000000ull) | (u64)(0xffffffffu - (unsigned int)i);
+            if (cv == 0ull) v = 0ull;  // empty slot
+        }
+        keys[i] = v;
+    }
+    __syncthreads();
+    bitonic_sort_desc(keys, Npad);
+
+    const int nbox = q.c.has_vel ? 9 : 7;
+    const int t = threadIdx.x;
+    int valid = 0;
+    float box[9];
+    float score = 0.f;
+    int label = 0;
+    if (t < K && keys[t] != 0ull) {
+        const u64 kv = keys[t];
+        const int pos = (int)(0xffffffffu - (unsigned int)(kv & 0xffffffffull));
+        label = pos / K;
+        const int pix = (int)(0xffffffffu - (unsigned int)(cand[pos] & 0xffffffffull));
+        score = __uint_as_float((unsigned int)(kv >> 32));
+        const int yi = pix / q.c.W, xi = pix - yi * q.c.W;
+        const size_t ro = (size_t)pix * q.c.reg_ld;
+        const float cx = q.center[ro + 0], cy = q.center[ro + 1];
+        float xs = __fadd_rn((float)xi, cx), ys = __fadd_rn((float)yi, cy);
+        xs = __fadd_rn(__fmul_rn(__fmul_rn(xs, q.c.feature_map_stride), q.c.voxel_size[0]), q.c.pc_range_min[0]);
+        ys = __fadd_rn(__fmul_rn(__fmul_rn(ys, q.c.feature_map_stride), q.c.voxel_size[1]), q.c.pc_range_min[1]);
+        box[0] = xs;
+        box[1] = ys;
+        box[2] = q.center_z[ro];
+        box[3] = expf(q.dim[ro + 0]);
+        box[4] = expf(q.dim[ro + 1]);
+        box[5] = expf(q.dim[ro + 2]);
+        box[6] = atan2f(q.rot[ro + 1], q.rot[ro + 0]);  // rot = (cos, sin)
+        box[7] = box[8] = 0.f;
+        if (q.c.has_vel) { box[7] = q.vel[ro + 0]; box[8] = q.vel[ro + 1]; }
+        valid = 1;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) valid &= (box[j] >= q.c.post_center_range[j]) && (box[j] <= q.c.post_center_range[3 + j]);
+        if (q.c.score_thresh >= 0.f) valid &= score > q.c.score_thresh;
+    }
+    int total;
+    const int dst = block_scan_excl_1024(valid, sh, &total);
+    if (valid) {
+        for (int j = 0; j < nbox; ++j) boxes_out[(size_t)dst * nbox + j] = box[j];
+        scores_out[dst] = score;
+        labels_out[dst] = label;
+    }
+    if (threadIdx.x == 0) *count_out = total;
+}
+
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+extern "C" size_t aq3d_center_decode_workspace_bytes(const aq3d_decode_cfg *cfg) {
+    if (!cfg) return 0;
+    return (size_t)cfg->num_classes * cfg->K * sizeof(u64) + 256;
+}
+
+extern "C" int aq3d_center_decode(const float *hm, const float *center, const float *center_z, const float *dim,
+                                  const float *rot, const float *vel, const aq3d_decode_cfg *cfg, float *boxes_out,
+                                  float *scores_out, int32_t *labels_out, int32_t *count_out, void *workspace,
+                                  size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(hm && center && center_z && dim && rot && cfg && boxes_out && scores_out && labels_out && count_out && workspace,
+                 "aq3d_center_decode: null argument");
+    AQ3D_REQUIRE(!cfg->has_vel || vel, "aq3d_center_decode: has_vel without vel map");
+    AQ3D_REQUIRE(cfg->num_classes >= 1 && cfg->num_classes <= 16, "aq3d_center_decode: num_classes=%d", cfg->num_classes);
+    AQ3D_REQUIRE(cfg->K >= 1 && cfg->K <= 512, "aq3d_center_decode: K=%d not in 1..512", cfg->K);
+    AQ3D_REQUIRE(cfg->H > 0 && cfg->W > 0, "aq3d_center_decode: empty map");
+    if (workspace_bytes < aq3d_center_decode_workspace_bytes(cfg)) {
+        aq3d_set_error("aq3d_center_decode: workspace too small");
+        return AQ3D_ERR_WORKSPACE;
+    }
+    const int L = cfg->H * cfg->W, K = cfg->K;
+    const int Kpad = next_pow2(K);
+    u64 *cand = (u64 *)workspace;
+    size_t lds1 = (size_t)Kpad * 8 + 256 * 4 + 16 * 4;
+    hipLaunchKernelGGL(topk_per_class_kernel, dim3(cfg->num_classes), dim3(1024), lds1, stream, hm, cfg->hm_ld, L, K, Kpad, cand);
+    const int ncand = cfg->num_classes * K;
+    const int Npad = next_pow2(ncand);
+    DecodeParams q;
+    q.c = *cfg; q.center = center; q.center_z = center_z; q.dim = dim; q.rot = rot; q.vel = vel;
+    size_t lds2 = (size_t)Npad * 8;
+    if (lds2 > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(1024), lds2, stream, cand, ncand, Npad, q, boxes_out, scores_out, labels_out, count_out);
+    AQ3D_CHECK_LAUNCH("aq3d_center_decode");
+    return AQ3D_OK;
+}
+
+// ------------------------------------------------------------------ rotated BEV IoU
+// Convex clipping of two rotated rectangles by collecting edge-edge intersections and contained corners, ordering
+// them by angle around their centroid and summing the fan area — the reference's algorithm, tolerances included
+// (EPS 1e-8 on the parallel test, 1e-2 margin on the corner-containment test).
+struct P2 { float x, y; };
+#define IOU_EPS 1e-8f
+#define IOU_MARGIN 1e-2f
+
+__device__ __forceinline__ float cross3(const P2 &p1, const P2 &p2, const P2 &p0) {
+    return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y);
+}
+__device__ __forceinline__ float cross2(const P2 &a, const P2 &b) { return a.x * b.y - a.y * b.x; }
+
+__device__ __forceinline__ bool bbox_overlap(const P2 &p1, const P2 &p2, const P2 &q1, const P2 &q2) {
+    return fminf(p1.x, p2.x) <= fmaxf(q1.x, q2.x) && fminf(q1.x, q2.x) <= fmaxf(p1.x, p2.x) &&
+           fminf(p1.y, p2.y) <= fmaxf(q1.y, q2.y) && fminf(q1.y, q2.y) <= fmaxf(p1.y, p2.y);
+}
+
+__device__ __forceinline__ bool seg_intersection(const P2 &p1, const P2 &p0, const P2 &q1, const P2 &q0, P2 &ans) {
+    if (!bbox_overlap(p0, p1, q0, q1)) return false;
+    const float s1 = cross3(q0, p1, p0), s2 = cross3(p1, q1, p0);
+    const float s3 = cross3(p0, q1, q0), s4 = cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0.f && s3 * s4 > 0.f)) return false;
+    const float s5 = cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > IOU_EPS) {
+        ans.x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans.y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans.x = (b0 * c1 - b1 * c0) / D;
+        ans.y = (a1 * c0 - a0 * c1) / D;
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool corner_in_box(const float *box, const P2 &p) {
+    const float ac = cosf(-box[6]), as = sinf(-box[6]);
+    const float rx = (p.x - box[0]) * ac + (p.y - box[1]) * (-as);
+    const float ry = (p.x - box[0]) * as + (p.y - box[1]) * ac;
+    return fabsf(rx) < box[3] / 2 + IOU_MARGIN && fabsf(ry) < box[4] / 2 + IOU_MARGIN;
+}
+
+__device__ __forceinline__ void box_corners(const float *b, P2 *c) {
+    const float hx = b[3] / 2, hy = b[4] / 2;
+    const float x1 = b[0] - hx, y1 = b[1] - hy, x2 = b[0] + hx, y2 = b[1] + hy;
+    const float ac = cosf(b[6]), as = sinf(b[6]);
+    const float px[4] = {x1, x2, x2, x1}, py[4] = {y1, y1, y2, y2};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        c[k].x = (px[k] - b[0]) * ac + (py[k] - b[1]) * (-as) + b[0];
+        c[k].y = (px[k] - b[0]) * as + (py[k] - b[1]) * ac + b[1];
+    }
+    c[4] = c[0];
+}
+
+__device__ float rotated_overlap(const float *ba, const float *bb) {
+    P2 ca[5], cb[5], pts[16];
+    box_corners(ba, ca);
+    box_corners(bb, cb);
+    int cnt = 0;
+    P2 ctr = {0.f, 0.f};
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            P2 ip;
+            if (seg_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], ip)) {
+                ctr.x += ip.x; ctr.y += ip.y;
+                pts[cnt++] = ip;
+            }
+        }
+    for (int k = 0; k < 4; ++k) {
+        if (corner_in_box(ba, cb[k])) { ctr.x += cb[k].x; ctr.y += cb[k].y; pts[cnt++] = cb[k]; }
+        if (corner_in_box(bb, ca[k])) { ctr.x += ca[k].x; ctr.y += ca[k].y; pts[cnt++] = ca[k]; }
+    }
+    ctr.x /= cnt;
+    ctr.y /= cnt;
+    // bubble sort by polar angle around the centroid (same comparison as the reference: strict >)
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (atan2f(pts[i].y - ctr.y, pts[i].x - ctr.x) > atan2f(pts[i + 1].y - ctr.y, pts[i + 1].x - ctr.x)) {
+                P2 t = pts[i]; pts[i] = pts[i + 1]; pts[i + 1] = t;
+            }
+    float area = 0.f;
+    for (int k = 0; k < cnt - 1; ++k) {
+        P2 u = {pts[k].x - pts[0].x, pts[k].y - pts[0].y}, v = {pts[k + 1].x - pts[0].x, pts[k + 1].y - pts[0].y};
+        area += cross2(u, v);
+    }
+    return fabsf(area) / 2.0f;
+}
+
+__device__ __forceinline__ float iou_bev_dev(const float *a, const float *b) {
+    const float sa = a[3] * a[4], sb = b[3] * b[4];
+    const float ov = rotated_overlap(a, b);
+    return ov / fmaxf(sa + sb - ov, IOU_EPS);
+}
+
+// one wave per (row box, column block): lane j tests box (cb*64 + j) against the row box, ballot → one mask word
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes, int box_ld, const int *count, int cap,
+                                                      float thresh, int col_blocks, u64 *__restrict__ mask) {
+    int n = *count;
+    if (n > cap) n = cap;
+    const int row = blockIdx.x, cb = blockIdx.y;
+    if (row >= n) return;
+    const int rb = row >> 6;
+    u64 word = 0ull;
+    if (cb >= rb) {
+        const int j = cb * 64 + threadIdx.x;
+        bool sup = false;
+        if (j < n && j > row) {
+            float a[7], b[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) { a[k] = boxes[(size_t)row * box_ld + k]; b[k] = boxes[(size_t)j * box_ld + k]; }
+            sup = iou_bev_dev(a, b) > thresh;
+        }
+        word = __ballot(sup);
+    }
+    if (threadIdx.x == 0) mask[(size_t)row * col_blocks + cb] = word;
+}
+
+// greedy sweep by a single wave, 64 boxes per step; lane w owns removal word w (cap <= 4096 → <= 64 words)
+__global__ __launch_bounds__(64) void nms_sweep_kernel(const u64 *__restrict__ mask, const int *count, int cap, int col_blocks,
+                                                       int post_max, int *__restrict__ keep, int *__restrict__ keep_count) {
+    int n = *count;
+    if (n > cap) n = cap;
+    const int lane = threadIdx.x;
+    u64 remv = 0ull;
+    int num = 0;
+    const int nb = (n + 63) >> 6;
+    for (int b = 0; b < nb; ++b) {
+        const int row = b * 64 + lane;
+        const u64 diag = (row < n) ? mask[(size_t)row * col_blocks + b] : 0ull;
+        u64 cur = __shfl(remv, b, 64);
+        u64 kept = 0ull;
+        const int lim = min(64, n - b * 64);
+        for (int t = 0; t < lim; ++t) {
+            const u64 d = __shfl(diag, t, 64);
+            const bool take = !((cur >> t) & 1ull);
+            if (take) { kept |= 1ull << t; cur |= d; }
+        }
+        if ((kept >> lane) & 1ull) {
+            const int pos = num + __popcll(kept & ((1ull << lane) - 1ull));
+            if (pos < post_max) keep[pos] = row;
+        }
+        num += __popcll(kept);
+        if (lane > b && lane < col_blocks) {
+            u64 k2 = kept;
+            while (k2) {
+                const int t = __ffsll((long long)k2) - 1;
+                k2 &= k2 - 1ull;
+                remv |= mask[(size_t)(b * 64 + t) * col_blocks + lane];
+            }
+        }
+    }
+    if (lane == 0) *keep_count = num < post_max ? num : post_max;
+}
+
+extern "C" size_t aq3d_nms_workspace_bytes(int32_t cap) {
+    if (cap < 1) cap = 1;
+    return (size_t)cap * aq3d_div_up(cap, 64) * sizeof(u64) + 256;
+}
+
+extern "C" int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_t *count, int32_t cap, float thresh,
+                                int32_t post_max, int32_t *keep_out, int32_t *keep_count, void *workspace,
+                                size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(boxes && count && keep_out && keep_count && workspace, "aq3d_nms_rotated: null argument");
+    AQ3D_REQUIRE(cap >= 1 && cap <= 4096 && box_ld >= 7 && post_max >= 1, "aq3d_nms_rotated: cap=%d box_ld=%d post_max=%d", cap, box_ld, post_max);
+    if (workspace_bytes < aq3d_nms_workspace_bytes(cap)) {
+        aq3d_set_error("aq3d_nms_rotated: workspace too small");
+        return AQ3D_ERR_WORKSPACE;
+    }
+    const int col_blocks = aq3d_div_up(cap, 64);
+    u64 *mask = (u64 *)workspace;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap, col_blocks), dim3(64), 0, stream, boxes, box_ld, count, cap, thresh, col_blocks, mask);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, stream, mask, count, cap, col_blocks, post_max, keep_out, keep_count);
+    AQ3D_CHECK_LAUNCH("aq3d_nms_rotated");
+    return AQ3D_OK;
+}
+
+__global__ __launch_bounds__(256) void gather_dets_kernel(const float *__restrict__ boxes, int box_ld,
+                                                          const float *__restrict__ scores, const int *__restrict__ labels,
+                                                          const int *__restrict__ class_map, const int *__restrict__ keep,
+                                                          const int *keep_count, int cap, float *__restrict__ boxes_out,
+                                                          float *__restrict__ scores_out, long long *__restrict__ labels_out) {
+    int n = *keep_count;
+    if (n > cap) n = cap;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int src = keep[i];
+        for (int j = 0; j < box_ld; ++j) boxes_out[(size_t)i * box_ld + j] = boxes[(size_t)src * box_ld + j];
+        scores_out[i] = scores[src];
+        const int lab = labels[src];
+        labels_out[i] = (long long)(class_map ? class_map[lab] : lab) + 1;  // center_head.py:363
+    }
+}
+
+extern "C" int aq3d_gather_dets(const float *boxes, int32_t box_ld, const float *scores, const int32_t *labels,
+                                const int32_t *class_map, const int32_t *keep, const int32_t *keep_count, int32_t cap,
+                                float *boxes_out, float *scores_out, int64_t *labels_out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(boxes && scores && labels && keep && keep_count && boxes_out && scores_out && labels_out,
+                 "aq3d_gather_dets: null argument");
+    hipLaunchKernelGGL(gather_dets_kernel, dim3(aq3d_grid(cap, 256)), dim3(256), 0, stream, boxes, box_ld, scores, labels,
+                       class_map, keep, keep_count, cap, boxes_out, scores_out, (long long *)labels_out);
+    AQ3D_CHECK_LAUNCH("aq3d_gather_dets");
+    return AQ3D_OK;
+}

@@ -1,0 +1,269 @@
+// Sparse→dense scatter and the per-frame SmoothQuant parameter preparation of the dense int8 convs.
+//
+// Reference semantics:
+//   HeightCompression (pcdet/models/backbones_2d/map_to_bev/height_compression.py:19-23):
+//       dense()[b, c, z, y, x] = feats[m, c];  view → channel c*D + z.   We keep NHWC: out[b, y, x, c*D + z].
+//   SQConv2d.forward (quant/smoothquant.py:58-85):
+//       X = unfold(x) [L, Cin*k*k];  act_scale_j = max_l |X[l,j]|;  w_scale_j = max_oc |W[oc,j]|
+//       s_j = act_scale_j^alpha / w_scale_j^(1-alpha), s_j == 0 → 1;   W' = W * s;  X' = X / s
+//       W' → per-out-channel fake quant;  X' → per-tensor fake quant;  Y = X'q @ W'q^T
+//   The im2col matrix is never materialised here: column j = (c, kh, kw) of X is a shifted window of channel c,
+//   so act_scale_j is the abs-max of x[c] over that window.  Windows of stride-1/2, pad<=1 3x3 (or 1x1) convs are
+//   unions of 16 "pieces" (first / last / interior-even / interior-odd rows x the same for columns); one pass
+//   over the input produces the 16 x Cin piece maxima, and the per-tensor amax of X' follows analytically:
+//   max_l |X[l,j] / s_j| = act_scale_j / s_j (fp32 division is monotone), so no second pass is needed.
+#include "common.h"
+
+// ------------------------------------------------------------------ scatter
+__global__ __launch_bounds__(256) void scatter_dense_kernel(const float *__restrict__ feats,
+                                                            const int *__restrict__ coords, const int *count, int cap,
+                                                            int C, int D, int H, int W, int B, float *__restrict__ out) {
+    int n = *count;
+    if (n > cap) n = cap;
+    const long long total = (long long)n * C;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        int m = (int)(t / C), c = (int)(t - (long long)m * C);
+        const int4 q = reinterpret_cast<const int4 *>(coords)[m];  // b, z, y, x
+        if (q.x < 0 || q.x >= B || q.y < 0 || q.y >= D || q.z < 0 || q.z >= H || q.w < 0 || q.w >= W) continue;
+        out[(((size_t)q.x * H + q.z) * W + q.w) * ((size_t)C * D) + (size_t)c * D + q.y] = feats[t];
+    }
+}
+
+extern "C" int aq3d_scatter_dense(const float *feats, const int32_t *coords, const int32_t *count, int32_t cap,
+                                  int32_t C, const int32_t shape[3], int32_t batch_size, float *out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(feats && coords && count && out, "aq3d_scatter_dense: null argument");
+    AQ3D_REQUIRE(C > 0 && shape[0] > 0 && shape[1] > 0 && shape[2] > 0 && batch_size > 0, "aq3d_scatter_dense: bad sizes");
+    const size_t bytes = (size_t)batch_size * shape[1] * shape[2] * C * shape[0] * sizeof(float);
+    hipMemsetAsync(out, 0, bytes, stream);
+    hipLaunchKernelGGL(scatter_dense_kernel, dim3(aq3d_grid((int64_t)cap * C, 256)), dim3(256), 0, stream, feats, coords,
+                       count, cap, C, shape[0], shape[1], shape[2], batch_size, out);
+    AQ3D_CHECK_LAUNCH("aq3d_scatter_dense");
+    return AQ3D_OK;
+}
+
+// ------------------------------------------------------------------ piece abs-max
+__device__ __forceinline__ int piece_class(int i, int n) { return i == 0 ? 0 : (i == n - 1 ? 1 : 2 + (i & 1)); }
+
+// grid = (H, SEG). One block = one input row segment; thread = (channel quad, pixel lane).
+__global__ __launch_bounds__(256) void piece_absmax_kernel(const float *__restrict__ x, int H, int W, int C, int ldc,
+                                                           float *__restrict__ pieces) {
+    extern __shared__ unsigned int red[];  // [4 col classes][C]
+    const int h = blockIdx.x;
+    const int c4n = C >> 2;
+    const int lanes = 256 / c4n;  // pixel lanes per pass (C <= 1024)
+    const int cq = threadIdx.x % c4n, pl = threadIdx.x / c4n;
+    const int w_per = (W + gridDim.y - 1) / gridDim.y;
+    const int w0 = blockIdx.y * w_per, w1 = min(W, w0 + w_per);
+    for (int i = threadIdx.x; i < 4 * C; i += 256) red[i] = 0u;
+    __syncthreads();
+    float4 m[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) m[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pl < lanes) {
+        for (int w = w0 + pl; w < w1; w += lanes) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + ((size_t)h * W + w) * ldc + cq * 4);
+            const int cc = piece_class(w, W);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (cc == k) {
+                    m[k].x = fmaxf(m[k].x, fabsf(v.x));
+                    m[k].y = fmaxf(m[k].y, fabsf(v.y));
+                    m[k].z = fmaxf(m[k].z, fabsf(v.z));
+                    m[k].w = fmaxf(m[k].w, fabsf(v.w));
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            atomicMax(&red[k * C + cq * 4 + 0], __float_as_uint(m[k].x));
+            atomicMax(&red[k * C + cq * 4 + 1], __float_as_uint(m[k].y));
+            atomicMax(&red[k * C + cq * 4 + 2], __float_as_uint(m[k].z));
+            atomicMax(&red[k * C + cq * 4 + 3], __float_as_uint(m[k].w));
+        }
+    }
+    __syncthreads();
+    const int rc = piece_class(h, H);
+    unsigned int *dst = reinterpret_cast<unsigned int *>(pieces) + (size_t)rc * 4 * C;
+    for (int i = threadIdx.x; i < 4 * C; i += 256) {
+        unsigned int v = red[i];
+        if (v > dst[i]) atomicMax(&dst[i], v);
+    }
+}
+
+extern "C" int aq3d_piece_absmax(const float *x, int32_t H, int32_t W, int32_t C, int32_t ldc, float *pieces,
+                                 void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(x && pieces, "aq3d_piece_absmax: null argument");
+    AQ3D_REQUIRE(H >= 3 && W >= 3, "aq3d_piece_absmax: H=%d W=%d must be >= 3", H, W);
+    AQ3D_REQUIRE(C >= 4 && C <= 1024 && (C & 3) == 0 && (ldc & 3) == 0 && ldc >= C, "aq3d_piece_absmax: C=%d ldc=%d", C, ldc);
+    const int seg = H >= 128 ? 4 : 8;
+    hipLaunchKernelGGL(piece_absmax_kernel, dim3(H, seg), dim3(256), (size_t)4 * C * sizeof(unsigned int), stream, x, H, W,
+                       C, ldc, pieces);
+    AQ3D_CHECK_LAUNCH("aq3d_piece_absmax");
+    return AQ3D_OK;
+}
+
+// ------------------------------------------------------------------ SmoothQuant parameter block
+// layout (all offsets 256-B aligned):  s f32[K] | rinv f32[K] | out_mul f32[Cout] | scal f32[8] | wq i8[Cout*K]
+//   scal[0] = sx (activation quant scale qmax/amax_x, 0 if amax_x <= 2^-24), scal[1] = amax_x, scal[2] = 1/sx'
+static inline size_t sq_align(size_t v) { return (v + 255) / 256 * 256; }
+
+struct SqLayout {
+    size_t s, r, mul, scal, wq, total;
+};
+static SqLayout sq_layout(int Cin, int Cout, int ksize) {
+    const size_t K = (size_t)Cin * ksize * ksize;
+    SqLayout l;
+    l.s = 0;
+    l.r = l.s + sq_align(K * 4);
+    l.mul = l.r + sq_align(K * 4);
+    l.scal = l.mul + sq_align((size_t)Cout * 4);
+    l.wq = l.scal + 256;
+    l.total = l.wq + sq_align((size_t)Cout * K);
+    return l;
+}
+
+extern "C" size_t aq3d_sq_param_bytes(int32_t Cin, int32_t Cout, int32_t ksize) {
+    return sq_layout(Cin, Cout, ksize).total;
+}
+
+struct TapMasks {
+    unsigned short m[9];
+};
+
+// Inclusion of the 16 pieces in the sampling window of every tap; fails when a piece is only partly covered.
+static int build_tap_masks(const aq3d_conv2d_geom *g, TapMasks *tm) {
+    auto cls = [](int i, int n) { return i == 0 ? 0 : (i == n - 1 ? 1 : 2 + (i & 1)); };
+    for (int kh = 0; kh < g->ksize; ++kh) {
+        for (int kw = 0; kw < g->ksize; ++kw) {
+            int rows_hit[4] = {0, 0, 0, 0}, rows_all[4] = {0, 0, 0, 0};
+            int cols_hit[4] = {0, 0, 0, 0}, cols_all[4] = {0, 0, 0, 0};
+            for (int r = 0; r < g->H; ++r) {
+                int t = r - kh + g->pad;
+                bool hit = t >= 0 && t % g->stride == 0 && t / g->stride < g->Ho;
+                rows_all[cls(r, g->H)]++;
+                rows_hit[cls(r, g->H)] += hit;
+            }
+            for (int c = 0; c < g->W; ++c) {
+                int t = c - kw + g->pad;
+                bool hit = t >= 0 && t % g->stride == 0 && t / g->stride < g->Wo;
+                cols_all[cls(c, g->W)]++;
+                cols_hit[cls(c, g->W)] += hit;
+            }
+            unsigned short mask = 0;
+            for (int rc = 0; rc < 4; ++rc) {
+                if (rows_hit[rc] != 0 && rows_hit[rc] != rows_all[rc]) return -1;
+                for (int cc = 0; cc < 4; ++cc) {
+                    if (cols_hit[cc] != 0 && cols_hit[cc] != cols_all[cc]) return -1;
+                    if (rows_hit[rc] && cols_hit[cc]) mask |= (unsigned short)(1u << (rc * 4 + cc));
+                }
+            }
+            tm->m[kh * g->ksize + kw] = mask;
+        }
+    }
+    return 0;
+}
+
+__device__ __forceinline__ float block_max_1024(float v, float *sh) {
+    v = aq3d_wave_max(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) r = fmaxf(r, sh[w]);
+    __syncthreads();
+    return r;
+}
+
+// one block: smoothing scales + per-tensor activation scale
+__global__ __launch_bounds__(1024) void sq_scales_kernel(const float *__restrict__ pieces,
+                                                         const float *__restrict__ w_colmax, int Cin, int ntaps,
+                                                         TapMasks tm, float alpha, float qmax_a, float static_amax_x,
+                                                         float *__restrict__ s_out, float *__restrict__ r_out,
+                                                         float *__restrict__ scal) {
+    __shared__ float sh[16];
+    const int K = Cin * ntaps;
+    float tmax = 0.f;
+    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+        const int tap = j / Cin, c = j - tap * Cin;
+        const unsigned mask = tm.m[tap];
+        float a = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            if (mask & (1u << p)) a = fmaxf(a, pieces[p * Cin + c]);
+        float s = 1.f;
+        if (alpha >= 0.f) {
+            const float w = w_colmax[j];
+            // torch.pow(x, 0.5) takes the sqrt path; other exponents go through powf
+            if (alpha == 0.5f) s = __fdiv_rn(sqrtf(a), sqrtf(w));
+            else s = __fdiv_rn(powf(a, alpha), powf(w, 1.f - alpha));
+            if (s == 0.f) s = 1.f;
+        }
+        s_out[j] = s;
+        r_out[j] = __fdiv_rn(1.0f, s);
+        tmax = fmaxf(tmax, fabsf(__fdiv_rn(a, s)));
+    }
+    float amax_x = block_max_1024(tmax, sh);
+    if (static_amax_x > 0.f) amax_x = static_amax_x;
+    if (threadIdx.x == 0) {
+        const float eps = 1.0f / (float)(1 << 24);
+        float sx = __fdiv_rn(qmax_a, amax_x), dv = sx;
+        if (amax_x <= eps) { sx = 0.f; dv = 1.f; }
+        scal[0] = sx;
+        scal[1] = amax_x;
+        scal[2] = __fdiv_rn(1.0f, dv);
+    }
+}
+
+// one block per output channel: W' = W * s, per-row amax, int8 codes, combined dequant multiplier
+__global__ __launch_bounds__(256) void sq_weights_kernel(const float *__restrict__ weight, const float *__restrict__ s,
+                                                         int K, float qmax_w, const float *__restrict__ static_amax_w,
+                                                         const float *__restrict__ scal, int8_t *__restrict__ wq,
+                                                         float *__restrict__ out_mul) {
+    __shared__ float sh[16];
+    const int oc = blockIdx.x;
+    const float *wrow = weight + (size_t)oc * K;
+    float mx = 0.f;
+    for (int j = threadIdx.x; j < K; j += 256) mx = fmaxf(mx, fabsf(__fmul_rn(wrow[j], s[j])));
+    float amax = block_max_1024(mx, sh);
+    if (static_amax_w) amax = static_amax_w[oc];
+    const float eps = 1.0f / (float)(1 << 24);
+    float sw = __fdiv_rn(qmax_w, amax), dv = sw;
+    if (amax <= eps) { sw = 0.f; dv = 1.f; }
+    for (int j = threadIdx.x; j < K; j += 256) {
+        float q = rintf(__fmul_rn(__fmul_rn(wrow[j], s[j]), sw));
+        q = fminf(fmaxf(q, -qmax_w - 1.f), qmax_w);
+        wq[(size_t)oc * K + j] = (int8_t)(int)q;
+    }
+    if (threadIdx.x == 0) out_mul[oc] = __fmul_rn(scal[2], __fdiv_rn(1.0f, dv));
+}
+
+extern "C" int aq3d_sq_prep(const float *pieces, const float *weight, const float *w_colmax,
+                            const aq3d_conv2d_geom *g, float alpha, int32_t w_bits, int32_t a_bits,
+                            float static_amax_x, const float *static_amax_w, void *params, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(pieces && weight && g && params, "aq3d_sq_prep: null argument");
+    AQ3D_REQUIRE(alpha < 0.f || w_colmax, "aq3d_sq_prep: w_colmax needed when smoothing is on");
+    AQ3D_REQUIRE(g->ksize == 1 || g->ksize == 3, "aq3d_sq_prep: ksize=%d", g->ksize);
+    AQ3D_REQUIRE(g->stride >= 1 && g->pad >= 0 && g->H >= 3 && g->W >= 3, "aq3d_sq_prep: bad geometry");
+    AQ3D_REQUIRE(w_bits >= 2 && w_bits <= 8 && a_bits >= 2 && a_bits <= 8, "aq3d_sq_prep: int8 kernel needs bits <= 8 (w=%d a=%d)", w_bits, a_bits);
+    TapMasks tm;
+    if (build_tap_masks(g, &tm) != 0) {
+        aq3d_set_error("aq3d_sq_prep: a tap window covers a border piece only partly (H=%d W=%d k=%d s=%d p=%d)", g->H,
+                       g->W, g->ksize, g->stride, g->pad);
+        return AQ3D_ERR_UNSUPPORTED;
+    }
+    const SqLayout l = sq_layout(g->Cin, g->Cout, g->ksize);
+    char *base = (char *)params;
+    float *s = (float *)(base + l.s), *r = (float *)(base + l.r), *mul = (float *)(base + l.mul);
+    float *scal = (float *)(base + l.scal);
+    int8_t *wq = (int8_t *)(base + l.wq);
+    const int ntaps = g->ksize * g->ksize, K = g->Cin * ntaps;
+    const float qa = (float)((1 << (a_bits - 1)) - 1), qw = (float)((1 << (w_bits - 1)) - 1);
+    hipLaunchKernelGGL(sq_scales_kernel, dim3(1), dim3(1024), 0, stream, pieces, w_colmax, g->Cin, ntaps, tm, alpha, qa,
+                       static_amax_x, s, r, scal);
+    hipLaunchKernelGGL(sq_weights_kernel, dim3(g->Cout), dim3(256), 0, stream, weight, s, K, qw, static_amax_w, scal, wq,
+                       mul);
+    AQ3D_CHECK_LAUNCH("aq3d_sq_prep");
+    return AQ3D_OK;
+}

@@ -175,3 +175,163 @@ def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequan
                         _p(post_scale), _p(post_shift), _p(residual), _p(nbr), _p(count_out), cap_out, cin, cout, kvol,
                         FLAG_RELU if relu else 0, _p(y), _p(absmax_out), _stream()), "aq3d_spconv")
     return y
+
+
+# ------------------------------------------------------------------ sparse → dense
+def scatter_dense(feats, coords, count, shape, batch_size, out=None):
+    """→ f32 NHWC [B, H, W, C*D], channel = c*D + z (HeightCompression)."""
+    L = _lib.load()
+    cap, C = feats.shape
+    D, H, W = shape
+    if out is None:
+        out = torch.empty((batch_size, H, W, C * D), dtype=f32, device=feats.device)
+    check(L.aq3d_scatter_dense(_p(feats), _p(coords), _p(count), cap, C, I3(*shape), batch_size, _p(out), _stream()),
+          "aq3d_scatter_dense")
+    return out
+
+
+# ------------------------------------------------------------------ dense convs
+def conv_geom(H, W, Cin, Cout, ksize=3, stride=1, pad=1, in_ld=None, out_ld=None, out_coff=0, deconv=0, relu=False):
+    g = Conv2dGeom()
+    g.H, g.W, g.Cin, g.Cout, g.ksize, g.stride, g.pad = H, W, Cin, Cout, ksize, stride, pad
+    if deconv:
+        g.Ho, g.Wo = H, W
+    else:
+        g.Ho = (H + 2 * pad - ksize) // stride + 1
+        g.Wo = (W + 2 * pad - ksize) // stride + 1
+    g.in_ld = in_ld or Cin
+    g.out_ld = out_ld or Cout
+    g.out_coff = out_coff
+    g.deconv = deconv
+    g.relu = int(bool(relu))
+    return g
+
+
+def out_hw(g):
+    return (g.H * g.deconv, g.W * g.deconv) if g.deconv else (g.Ho, g.Wo)
+
+
+def piece_absmax(x, H, W, C, ldc=None, pieces=None):
+    """x f32 NHWC [H, W, ldc] (first C channels used) → pieces f32 [16, C]."""
+    L = _lib.load()
+    if pieces is None:
+        pieces = torch.zeros((16, C), dtype=f32, device=x.device)
+    check(L.aq3d_piece_absmax(_p(x), H, W, C, ldc or C, _p(pieces), _stream()), "aq3d_piece_absmax")
+    return pieces
+
+
+def sq_param_bytes(Cin, Cout, ksize):
+    return _lib.load().aq3d_sq_param_bytes(Cin, Cout, ksize)
+
+
+def sq_prep(pieces, weight_k, w_colmax, g, alpha, params=None, w_bits=8, a_bits=8, static_amax_x=0.0,
+            static_amax_w=None):
+    """weight_k f32 [Cout, K] with K ordered (kh, kw, c). → params block (uint8 tensor)."""
+    L = _lib.load()
+    if params is None:
+        params = torch.empty((sq_param_bytes(g.Cin, g.Cout, g.ksize),), dtype=torch.uint8, device=pieces.device)
+    check(L.aq3d_sq_prep(_p(pieces), _p(weight_k), _p(w_colmax), ctypes.byref(g), float(alpha if alpha is not None else -1.0),
+                         int(w_bits), int(a_bits), float(static_amax_x), _p(static_amax_w), _p(params), _stream()),
+          "aq3d_sq_prep")
+    return params
+
+
+def conv2d_i8(x, params, g, bias=None, post_scale=None, post_shift=None, out=None):
+    L = _lib.load()
+    Ho, Wo = out_hw(g)
+    y = out if out is not None else torch.empty((Ho, Wo, g.out_ld), dtype=f32, device=x.device)
+    check(L.aq3d_conv2d_i8(_p(x), _p(params), ctypes.byref(g), _p(bias), _p(post_scale), _p(post_shift), _p(y), _stream()),
+          "aq3d_conv2d_i8")
+    return y
+
+
+def conv2d_f32(x, weight_k, g, bias=None, post_scale=None, post_shift=None, out=None):
+    L = _lib.load()
+    Ho, Wo = out_hw(g)
+    y = out if out is not None else torch.empty((Ho, Wo, g.out_ld), dtype=f32, device=x.device)
+    check(L.aq3d_conv2d_f32(_p(x), _p(weight_k), ctypes.byref(g), _p(bias), _p(post_scale), _p(post_shift), _p(y), _stream()),
+          "aq3d_conv2d_f32")
+    return y
+
+
+def conv_weight_to_k(weight_oihw):
+    """nn.Conv2d weight [O, I, kh, kw] → [O, K] with K ordered (kh, kw, c)."""
+    O = weight_oihw.shape[0]
+    return weight_oihw.permute(0, 2, 3, 1).reshape(O, -1).contiguous()
+
+
+def deconv_weight_to_k(weight_iohw):
+    """nn.ConvTranspose2d weight [I, O, d, d] (kernel == stride) → [(i*d + j)*O + o, I]."""
+    I = weight_iohw.shape[0]
+    return weight_iohw.permute(2, 3, 1, 0).reshape(-1, I).contiguous()
+
+
+# ------------------------------------------------------------------ decode + NMS
+def make_decode_cfg(H, W, num_classes, K, has_vel, feature_map_stride, voxel_size, pc_range, post_center_range,
+                    score_thresh, hm_ld, reg_ld):
+    c = DecodeCfg()
+    c.H, c.W, c.num_classes, c.K, c.has_vel = H, W, num_classes, K, int(bool(has_vel))
+    c.feature_map_stride = float(feature_map_stride)
+    for j in range(2):
+        c.voxel_size[j] = float(voxel_size[j])
+        c.pc_range_min[j] = float(pc_range[j])
+    for j in range(6):
+        c.post_center_range[j] = float(post_center_range[j])
+    c.score_thresh = float(score_thresh) if score_thresh is not None else -1.0
+    c.hm_ld, c.reg_ld = hm_ld, reg_ld
+    return c
+
+
+def center_decode(hm, center, center_z, dim, rot, vel, cfg, workspace=None, out=None):
+    """→ (boxes f32 [K, 7|9], scores f32 [K], labels i32 [K], count i32 [1]); rows beyond count are undefined."""
+    L = _lib.load()
+    dev = hm.device
+    nb = 9 if cfg.has_vel else 7
+    if out is None:
+        boxes = torch.zeros((cfg.K, nb), dtype=f32, device=dev)
+        scores = torch.zeros((cfg.K,), dtype=f32, device=dev)
+        labels = torch.zeros((cfg.K,), dtype=i32, device=dev)
+        count = torch.zeros((1,), dtype=i32, device=dev)
+    else:
+        boxes, scores, labels, count = out
+    need = L.aq3d_center_decode_workspace_bytes(ctypes.byref(cfg))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
+    check(L.aq3d_center_decode(_p(hm), _p(center), _p(center_z), _p(dim), _p(rot), _p(vel), ctypes.byref(cfg), _p(boxes),
+                               _p(scores), _p(labels), _p(count), _p(workspace), workspace.numel(), _stream()),
+          "aq3d_center_decode")
+    return boxes, scores, labels, count
+
+
+def nms_rotated(boxes, count, thresh, post_max, workspace=None, out=None):
+    """boxes f32 [cap, ld] sorted by descending score → (keep i32 [cap], keep_count i32 [1])."""
+    L = _lib.load()
+    cap, ld = boxes.shape
+    dev = boxes.device
+    if out is None:
+        keep = torch.zeros((cap,), dtype=i32, device=dev)
+        kc = torch.zeros((1,), dtype=i32, device=dev)
+    else:
+        keep, kc = out
+    need = L.aq3d_nms_workspace_bytes(cap)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
+    check(L.aq3d_nms_rotated(_p(boxes), ld, _p(count), cap, float(thresh), int(post_max), _p(keep), _p(kc), _p(workspace),
+                             workspace.numel(), _stream()), "aq3d_nms_rotated")
+    return keep, kc
+
+
+def gather_dets(boxes, scores, labels, class_map, keep, keep_count, out=None):
+    """→ (boxes f32 [cap, ld], scores f32 [cap], labels i64 [cap]) rows [0, keep_count) valid; labels are 1-based."""
+    L = _lib.load()
+    cap, ld = boxes.shape
+    dev = boxes.device
+    if out is None:
+        bo = torch.zeros((cap, ld), dtype=f32, device=dev)
+        so = torch.zeros((cap,), dtype=f32, device=dev)
+        lo = torch.zeros((cap,), dtype=torch.int64, device=dev)
+    else:
+        bo, so, lo = out
+    check(L.aq3d_gather_dets(_p(boxes), ld, _p(scores), _p(labels), _p(class_map), _p(keep), _p(keep_count), cap, _p(bo),
+                             _p(so), _p(lo), _stream()), "aq3d_gather_dets")
+    return bo, so, lo

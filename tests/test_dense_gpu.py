@@ -1,0 +1,211 @@
+"""GPU parity: sparse→dense scatter, SmoothQuant int8 conv, fp32 conv / deconv, decode and rotated NMS vs the oracle.
+
+Bars: scatter exact; int8 conv within 2e-5 of the output scale (int32 accumulation is exact, the reference's fp32
+matmul is not — SURVEY.md §8a row 13 measured 3e-6); fp32 convs within 2e-5; decode scores/boxes within 1e-5 with
+identical ranking; NMS keep lists identical.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import decode as OD
+from oracle import dense as ODN
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(t):   # [1,C,H,W] → [H,W,C]
+    return t[0].permute(1, 2, 0).contiguous()
+
+
+def test_scatter_dense_exact(dev):
+    from amdq3d import ops
+    rng = np.random.default_rng(0)
+    D, H, W, C, B = 2, 24, 20, 128, 2
+    idx = np.unique(np.stack([rng.integers(0, B, 700), rng.integers(0, D, 700), rng.integers(0, H, 700),
+                              rng.integers(0, W, 700)], 1).astype(np.int32), axis=0)
+    rng.shuffle(idx)
+    m = len(idx)
+    feats = rng.normal(0, 1, (m, C)).astype(np.float32)
+    ref = ODN.height_compression(feats, idx, (D, H, W), B)          # [B, C*D, H, W]
+    cap = m + 9
+    fc = torch.zeros((cap, C), device=dev); fc[:m] = torch.from_numpy(feats).to(dev)
+    cc = torch.zeros((cap, 4), dtype=torch.int32, device=dev); cc[:m] = torch.from_numpy(idx).to(dev)
+    cnt = torch.tensor([m], dtype=torch.int32, device=dev)
+    out = ops.scatter_dense(fc, cc, cnt, (D, H, W), B).cpu()          # [B, H, W, C*D]
+    np.testing.assert_array_equal(out.permute(0, 3, 1, 2).numpy(), ref.numpy())
+
+
+CASES_I8 = [
+    # Cin, Cout, H, W, stride, alpha, bias, bn
+    (64, 64, 24, 20, 1, 0.5, True, True),
+    (128, 128, 40, 36, 1, 0.5, False, True),
+    (128, 256, 36, 40, 2, 0.5, False, True),
+    (256, 128, 21, 19, 1, 0.5, False, False),
+    (64, 64, 16, 16, 1, None, True, False),
+    (512, 64, 20, 24, 1, 0.3, True, True),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,stride,alpha,use_bias,use_bn", CASES_I8)
+def test_conv2d_i8_vs_sqconv2d(dev, Cin, Cout, H, W, stride, alpha, use_bias, use_bn):
+    from amdq3d import ops
+    g_ = torch.Generator().manual_seed(Cin * 3 + Cout + H)
+    x = torch.relu(torch.randn(1, Cin, H, W, generator=g_)) * (torch.rand(1, Cin, 1, 1, generator=g_) * 3 + 0.1)
+    x[:, :, 0, :] *= 2.5      # make border pieces matter for the column abs-max
+    x[:, :, :, -1] *= 1.7
+    w = torch.randn(Cout, Cin, 3, 3, generator=g_) / np.sqrt(9 * Cin)
+    bias = torch.randn(Cout, generator=g_) * 0.1 if use_bias else None
+    ref, st = ODN.sq_conv2d(x, w, bias, stride, 1, alpha, return_stats=True)
+    ps = pt = None
+    if use_bn:
+        ps = torch.rand(Cout, generator=g_) + 0.5
+        pt = torch.randn(Cout, generator=g_) * 0.1
+        ref = torch.relu(ref * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))
+    xg = _nhwc(x).to(dev)
+    geom = ops.conv_geom(H, W, Cin, Cout, 3, stride, 1, relu=use_bn)
+    wk = ops.conv_weight_to_k(w).to(dev)
+    wcol = wk.abs().max(dim=0)[0].contiguous()
+    pieces = ops.piece_absmax(xg, H, W, Cin)
+    params = ops.sq_prep(pieces, wk, wcol, geom, alpha)
+    y = ops.conv2d_i8(xg, params, geom, bias=None if bias is None else bias.to(dev),
+                      post_scale=None if ps is None else ps.to(dev), post_shift=None if pt is None else pt.to(dev))
+    y = y.cpu().permute(2, 0, 1)[None]
+    K = 9 * Cin
+    amax_x = params.cpu()[2 * ((K * 4 + 255) // 256 * 256) + ((Cout * 4 + 255) // 256 * 256):][:8].view(torch.float32)[1].item()
+    assert amax_x == pytest.approx(float(st["amax_x"]), rel=1e-6)
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert float((y - ref).abs().max()) <= tol
+
+
+CASES_F32 = [
+    # Cin, Cout, H, W, ksize, stride, pad
+    (64, 64, 24, 20, 3, 1, 1),
+    (64, 3, 24, 20, 3, 1, 1),
+    (64, 1, 17, 23, 3, 1, 1),
+    (128, 256, 20, 24, 3, 2, 1),
+    (512, 64, 12, 16, 3, 1, 1),
+    (128, 128, 33, 31, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,k,stride,pad", CASES_F32)
+def test_conv2d_f32(dev, Cin, Cout, H, W, k, stride, pad):
+    from amdq3d import ops
+    g_ = torch.Generator().manual_seed(Cin + Cout + H + k)
+    x = torch.randn(1, Cin, H, W, generator=g_)
+    w = torch.randn(Cout, Cin, k, k, generator=g_) / np.sqrt(k * k * Cin)
+    b = torch.randn(Cout, generator=g_) * 0.1
+    ps = torch.rand(Cout, generator=g_) + 0.5
+    pt = torch.randn(Cout, generator=g_) * 0.1
+    ref = torch.relu((F.conv2d(x, w, b, stride, pad)) * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))
+    out_ld = max(4, (Cout + 3) // 4 * 4) + 4
+    geom = ops.conv_geom(H, W, Cin, Cout, k, stride, pad, out_ld=out_ld, out_coff=4, relu=True)
+    buf = torch.full((geom.Ho, geom.Wo, out_ld), -7.0, device=dev)
+    ops.conv2d_f32(_nhwc(x).to(dev), ops.conv_weight_to_k(w).to(dev), geom, b.to(dev), ps.to(dev), pt.to(dev), out=buf)
+    y = buf.cpu()
+    assert float((y[..., :4] + 7.0).abs().max()) == 0.0          # channels outside [coff, coff+Cout) untouched
+    y = y[..., 4:4 + Cout].permute(2, 0, 1)[None]
+    assert float((y - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("Cin,Cout,H,W,d", [(128, 256, 20, 24, 1), (256, 256, 10, 12, 2), (64, 32, 7, 9, 2)])
+def test_deconv_f32(dev, Cin, Cout, H, W, d):
+    from amdq3d import ops
+    g_ = torch.Generator().manual_seed(Cin + Cout + d)
+    x = torch.randn(1, Cin, H, W, generator=g_)
+    w = torch.randn(Cin, Cout, d, d, generator=g_) / np.sqrt(Cin)
+    ps = torch.rand(Cout, generator=g_) + 0.5
+    pt = torch.randn(Cout, generator=g_) * 0.1
+    ref = torch.relu(F.conv_transpose2d(x, w, None, stride=d) * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))
+    geom = ops.conv_geom(H, W, Cin, Cout, 1, 1, 0, out_ld=2 * Cout, out_coff=Cout, deconv=d, relu=True)
+    buf = torch.zeros((H * d, W * d, 2 * Cout), device=dev)
+    ops.conv2d_f32(_nhwc(x).to(dev), ops.deconv_weight_to_k(w).to(dev), geom, None, ps.to(dev), pt.to(dev), out=buf)
+    y = buf.cpu()[..., Cout:].permute(2, 0, 1)[None]
+    assert float((y - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def _head_maps(H, W, ncls, seed, peaks=300):
+    rng = np.random.default_rng(seed)
+    hm = rng.normal(-4.0, 1.0, (ncls, H, W)).astype(np.float32)
+    for _ in range(peaks):
+        hm[rng.integers(0, ncls), rng.integers(0, H), rng.integers(0, W)] = rng.uniform(-1.0, 4.0)
+    hm[0, 3, 5] = hm[1, 7, 9] = hm[0, 11, 2] = 2.5            # exact score ties (across classes and inside one)
+    center = rng.uniform(0, 1, (2, H, W)).astype(np.float32)
+    center_z = rng.uniform(-1.5, 3.5, (1, H, W)).astype(np.float32)
+    dim = rng.normal(0.5, 0.4, (3, H, W)).astype(np.float32)
+    rot = rng.normal(0, 1, (2, H, W)).astype(np.float32)
+    return hm, center, center_z, dim, rot
+
+
+@pytest.mark.parametrize("H,W,ncls,K", [(47, 47, 3, 100), (188, 188, 3, 500), (20, 12, 1, 500)])
+def test_center_decode(dev, H, W, ncls, K):
+    from amdq3d import ops
+    hm, center, center_z, dim, rot = _head_maps(H, W, ncls, seed=H + K)
+    pc_range = [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
+    b_ref, s_ref, l_ref = OD.decode_bbox_from_heatmap(OD.sigmoid(hm), center, center_z, np.exp(dim), rot, None, pc_range,
+                                                      [0.1, 0.1, 0.15], 8, K, 0.1, pc_range)
+    # device layout: one NHWC head buffer [H*W, 16]: hm 0.., center 4,5, z 6, dim 8..10, rot 12,13
+    buf = np.zeros((H * W, 16), np.float32)
+    buf[:, 0:ncls] = hm.reshape(ncls, -1).T
+    buf[:, 4:6] = center.reshape(2, -1).T
+    buf[:, 6:7] = center_z.reshape(1, -1).T
+    buf[:, 8:11] = dim.reshape(3, -1).T
+    buf[:, 12:14] = rot.reshape(2, -1).T
+    t = torch.from_numpy(buf).to(dev)
+    cfg = ops.make_decode_cfg(H, W, ncls, K, False, 8, [0.1, 0.1], pc_range, pc_range, 0.1, 16, 16)
+    boxes, scores, labels, count = ops.center_decode(t, t[:, 4:], t[:, 6:], t[:, 8:], t[:, 12:], None, cfg)
+    n = int(count.item())
+    assert n == len(s_ref)
+    np.testing.assert_array_equal(labels[:n].cpu().numpy(), l_ref)
+    np.testing.assert_allclose(scores[:n].cpu().numpy(), s_ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(boxes[:n].cpu().numpy(), b_ref, rtol=1e-5, atol=1e-5)
+
+
+def _boxes(n, seed):
+    rng = np.random.default_rng(seed)
+    ctr = rng.uniform(-30, 30, (max(n // 6, 1), 2))
+    b = np.zeros((n, 7), np.float32)
+    which = rng.integers(0, len(ctr), n)
+    b[:, 0:2] = ctr[which] + rng.normal(0, 0.6, (n, 2))
+    b[:, 2] = rng.uniform(-1, 1, n)
+    b[:, 3] = rng.uniform(3.5, 5.0, n); b[:, 4] = rng.uniform(1.6, 2.2, n); b[:, 5] = rng.uniform(1.4, 1.9, n)
+    b[:, 6] = rng.uniform(-np.pi, np.pi, n)
+    return b
+
+
+@pytest.mark.parametrize("n,thresh,post", [(500, 0.7, 500), (500, 0.2, 83), (65, 0.1, 500), (1, 0.7, 500), (1000, 0.5, 500)])
+def test_nms_rotated_keep_list(dev, n, thresh, post):
+    from amdq3d import ops
+    b = _boxes(n, seed=n)
+    ref = OD.nms_sorted(b, thresh)[:post]
+    cap = n + 12
+    t = torch.zeros((cap, 7), device=dev); t[:n] = torch.from_numpy(b).to(dev)
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    keep, kc = ops.nms_rotated(t, cnt, thresh, post)
+    m = int(kc.item())
+    assert m == len(ref)
+    np.testing.assert_array_equal(keep[:m].cpu().numpy(), ref)
+    iou_dev_vs_ref = OD.iou_bev(b[:64], b[:64])
+    assert np.isfinite(iou_dev_vs_ref).all()
+
+
+def test_nms_empty_and_gather(dev):
+    from amdq3d import ops
+    t = torch.zeros((16, 7), device=dev)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+    keep, kc = ops.nms_rotated(t, cnt, 0.7, 10)
+    assert int(kc.item()) == 0
+    b = _boxes(40, 3)
+    t = torch.from_numpy(b).to(dev)
+    scores = torch.linspace(0.9, 0.2, 40, device=dev)
+    labels = (torch.arange(40, device=dev) % 3).to(torch.int32)
+    cnt = torch.tensor([40], dtype=torch.int32, device=dev)
+    keep, kc = ops.nms_rotated(t, cnt, 0.5, 500)
+    cmap = torch.tensor([2, 0, 1], dtype=torch.int32, device=dev)
+    bo, so, lo = ops.gather_dets(t, scores, labels, cmap, keep, kc)
+    m = int(kc.item())
+    k = keep[:m].long()
+    assert torch.equal(bo[:m], t[k]) and torch.equal(so[:m], scores[k])
+    assert torch.equal(lo[:m], cmap[labels[k].long()].long() + 1)
