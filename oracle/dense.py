@@ -17,6 +17,24 @@ def _fq(t, amax, bits):
     return torch.from_numpy(Q.fake_quant(t.numpy(), np.asarray(amax, dtype=np.float32), bits))
 
 
+def smooth_scale(act_scale, w_scale, alpha):
+    """quant/smoothquant.py:75-76: act_scale**alpha / w_scale**(1-alpha), zeros → 1.
+
+    torch.pow(x, 0.5) is computed as sqrt(x). torch's CPU sqrt is a vectorised routine whose last bit varies with the
+    host's SIMD level (observed: 16 vs 260 of 1152 values off by one ulp on two machines), while CUDA/HIP sqrt and
+    numpy's are IEEE correctly rounded — so the restatement pins the IEEE result."""
+    a = act_scale.numpy().astype(np.float32)
+    w = w_scale.numpy().astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if alpha == 0.5:
+            s = np.sqrt(a) / np.sqrt(w)
+        else:
+            s = np.power(a, np.float32(alpha)) / np.power(w, np.float32(1 - alpha))
+    s = s.astype(np.float32)
+    s[s == 0] = 1
+    return torch.from_numpy(s)
+
+
 def sq_conv2d(x, weight, bias, stride, padding, alpha, w_bits=8, a_bits=8, amax_x=None, amax_w=None, return_stats=False):
     """x [B,C,H,W], weight [O,I,k,k]. alpha=None → no smoothing (plain per-tensor act / per-oc weight fake quant)."""
     O, I, k, _ = weight.shape
@@ -28,8 +46,7 @@ def sq_conv2d(x, weight, bias, stride, padding, alpha, w_bits=8, a_bits=8, amax_
     if alpha is not None:
         w_scale = w.abs().max(dim=0)[0]
         act_scale = cols.abs().max(dim=0)[0]
-        scale = act_scale ** alpha / w_scale ** (1 - alpha)
-        scale[scale == 0] = 1
+        scale = smooth_scale(act_scale, w_scale, alpha)
         w = w * scale
         cols = cols / scale
     aw = Q.reduce_amax(w.numpy(), axis=0) if amax_w is None else np.asarray(amax_w, np.float32).reshape(O, 1)

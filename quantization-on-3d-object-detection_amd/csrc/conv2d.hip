@@ -14,6 +14,7 @@
 // ends up with 4 consecutive output channels of one pixel → one 16-byte NHWC store per accumulator tile.
 // Workgroup = 256 threads = 2x2 waves; wave tile = (TI*16) channels x (TJ*16) pixels.
 #include "common.h"
+#include "sq_layout.h"
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -351,15 +352,13 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
     AQ3D_REQUIRE(g->deconv == 0, "aq3d_conv2d_i8: deconv unsupported");
     AQ3D_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->ksize) / g->stride + 1 && g->Wo == (g->W + 2 * g->pad - g->ksize) / g->stride + 1,
                  "aq3d_conv2d_i8: Ho/Wo inconsistent with geometry");
-    // parameter block layout must match dense_prep.hip::sq_layout
-    const size_t K = (size_t)g->Cin * g->ksize * g->ksize;
-    auto al = [](size_t v) { return (v + 255) / 256 * 256; };
+    const SqLayout l = sq_layout(g->Cin, g->Cout, g->ksize);
     const char *base = (const char *)params;
-    a.s = (const float *)base;
-    a.rinv = (const float *)(base + al(K * 4));
-    a.out_mul = (const float *)(base + 2 * al(K * 4));
-    a.scal = (const float *)(base + 2 * al(K * 4) + al((size_t)g->Cout * 4));
-    a.w = base + 2 * al(K * 4) + al((size_t)g->Cout * 4) + 256;
+    a.s = (const float *)(base + l.s);
+    a.rinv = (const float *)(base + l.r);
+    a.out_mul = (const float *)(base + l.mul);
+    a.scal = (const float *)(base + l.scal);
+    a.w = base + l.wq;
     const int L = g->Ho * g->Wo;
     if (g->Cout >= 128) {
         if (L >= 128 * 200) {

@@ -13,6 +13,7 @@
 //   over the input produces the 16 x Cin piece maxima, and the per-tensor amax of X' follows analytically:
 //   max_l |X[l,j] / s_j| = act_scale_j / s_j (fp32 division is monotone), so no second pass is needed.
 #include "common.h"
+#include "sq_layout.h"
 
 // ------------------------------------------------------------------ scatter
 __global__ __launch_bounds__(256) void scatter_dense_kernel(const float *__restrict__ feats,
@@ -105,25 +106,6 @@ extern "C" int aq3d_piece_absmax(const float *x, int32_t H, int32_t W, int32_t C
 }
 
 // ------------------------------------------------------------------ SmoothQuant parameter block
-// layout (all offsets 256-B aligned):  s f32[K] | rinv f32[K] | out_mul f32[Cout] | scal f32[8] | wq i8[Cout*K]
-//   scal[0] = sx (activation quant scale qmax/amax_x, 0 if amax_x <= 2^-24), scal[1] = amax_x, scal[2] = 1/sx'
-static inline size_t sq_align(size_t v) { return (v + 255) / 256 * 256; }
-
-struct SqLayout {
-    size_t s, r, mul, scal, wq, total;
-};
-static SqLayout sq_layout(int Cin, int Cout, int ksize) {
-    const size_t K = (size_t)Cin * ksize * ksize;
-    SqLayout l;
-    l.s = 0;
-    l.r = l.s + sq_align(K * 4);
-    l.mul = l.r + sq_align(K * 4);
-    l.scal = l.mul + sq_align((size_t)Cout * 4);
-    l.wq = l.scal + 256;
-    l.total = l.wq + sq_align((size_t)Cout * K);
-    return l;
-}
-
 extern "C" size_t aq3d_sq_param_bytes(int32_t Cin, int32_t Cout, int32_t ksize) {
     return sq_layout(Cin, Cout, ksize).total;
 }
@@ -219,13 +201,14 @@ __global__ __launch_bounds__(1024) void sq_scales_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void sq_weights_kernel(const float *__restrict__ weight, const float *__restrict__ s,
                                                          int K, float qmax_w, const float *__restrict__ static_amax_w,
                                                          const float *__restrict__ scal, int8_t *__restrict__ wq,
-                                                         float *__restrict__ out_mul) {
+                                                         float *__restrict__ out_mul, float *__restrict__ amax_w_out) {
     __shared__ float sh[16];
     const int oc = blockIdx.x;
     const float *wrow = weight + (size_t)oc * K;
     float mx = 0.f;
     for (int j = threadIdx.x; j < K; j += 256) mx = fmaxf(mx, fabsf(__fmul_rn(wrow[j], s[j])));
     float amax = block_max_1024(mx, sh);
+    if (threadIdx.x == 0) amax_w_out[oc] = amax;   // dynamic per-oc amax of W*s (what a max calibrator collects)
     if (static_amax_w) amax = static_amax_w[oc];
     const float eps = 1.0f / (float)(1 << 24);
     float sw = __fdiv_rn(qmax_w, amax), dv = sw;
@@ -256,14 +239,14 @@ extern "C" int aq3d_sq_prep(const float *pieces, const float *weight, const floa
     const SqLayout l = sq_layout(g->Cin, g->Cout, g->ksize);
     char *base = (char *)params;
     float *s = (float *)(base + l.s), *r = (float *)(base + l.r), *mul = (float *)(base + l.mul);
-    float *scal = (float *)(base + l.scal);
+    float *scal = (float *)(base + l.scal), *amaxw = (float *)(base + l.amaxw);
     int8_t *wq = (int8_t *)(base + l.wq);
     const int ntaps = g->ksize * g->ksize, K = g->Cin * ntaps;
     const float qa = (float)((1 << (a_bits - 1)) - 1), qw = (float)((1 << (w_bits - 1)) - 1);
     hipLaunchKernelGGL(sq_scales_kernel, dim3(1), dim3(1024), 0, stream, pieces, w_colmax, g->Cin, ntaps, tm, alpha, qa,
                        static_amax_x, s, r, scal);
     hipLaunchKernelGGL(sq_weights_kernel, dim3(g->Cout), dim3(256), 0, stream, weight, s, K, qw, static_amax_w, scal, wq,
-                       mul);
+                       mul, amaxw);
     AQ3D_CHECK_LAUNCH("aq3d_sq_prep");
     return AQ3D_OK;
 }

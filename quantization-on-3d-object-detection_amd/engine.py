@@ -1,0 +1,605 @@
+"""Device plan of the CenterPoint hot path: compiles the parameter containers (modules.py) and quantisation
+descriptors (quant.py) into preallocated device buffers + an ordered list of HIP kernel launches, then runs a frame.
+
+One forward = voxelize → rulebook (5 index levels) → 21 sparse convs → sparse→dense → 12 BEV convs + 2 deblocks →
+shared conv + head branches → decode → rotated NMS, all enqueued on the current stream with NO device→host
+synchronisation until the final read of the per-sample detection counts. Dynamic sizes stay on the device.
+
+Memory is laid out for a 288 GB HBM3E part: every conv owns its output buffer at full capacity (no reuse
+juggling), gather tables are materialised per index level ([cap, 27] i32), and all per-frame statistics (abs-max
+slots, piece maxima, counters) live in ONE arena cleared by a single memset per frame.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .modules import SparseBasicBlock, SparseConvolution, SparseSequential
+from .quant import QConvNd, QuantConv2d, SQConv2d, _QuantConv2dBase, quantize_weight_rows, surgery_epoch
+
+f32, i32 = torch.float32, torch.int32
+
+
+def _np(t):
+    return t.detach().float().cpu().numpy()
+
+
+def fold_bn(bn):
+    """eval-mode BatchNorm → (scale, shift) with IEEE fp32 numpy ops: y = x*scale + shift."""
+    w, b = _np(bn.weight), _np(bn.bias)
+    mean, var = _np(bn.running_mean), _np(bn.running_var)
+    scale = (w / np.sqrt(var + np.float32(bn.eps))).astype(np.float32)
+    shift = (b - mean * scale).astype(np.float32)
+    return scale, shift
+
+
+class _Arena:
+    """Bump allocator over one zero-initialised float32 tensor that is memset once per frame."""
+
+    def __init__(self, device):
+        self.device = device
+        self.size = 0
+        self.buf = None
+        self.views = []
+
+    def alloc(self, n):
+        off = self.size
+        self.size += (int(n) + 63) // 64 * 64
+        self.views.append((off, int(n)))
+        return len(self.views) - 1
+
+    def finalize(self):
+        self.buf = torch.zeros((max(self.size, 64),), dtype=f32, device=self.device)
+
+    def view(self, handle, shape=None, dtype=f32):
+        off, n = self.views[handle]
+        v = self.buf[off:off + n]
+        if dtype != f32:
+            v = v.view(dtype)
+        return v.view(shape) if shape is not None else v
+
+    def clear(self):
+        self.buf.zero_()
+
+
+class SparseTensorView:
+    """What the reference hands around as spconv.SparseConvTensor: features/indices of the live rows."""
+
+    def __init__(self, features, indices, count, spatial_shape, batch_size):
+        self._f, self._i, self._c = features, indices, count
+        self.spatial_shape, self.batch_size = spatial_shape, batch_size
+
+    @property
+    def features(self):
+        return self._f[:int(self._c.item())]
+
+    @property
+    def indices(self):
+        return self._i[:int(self._c.item())]
+
+    def dense_nhwc(self):
+        D, H, W = self.spatial_shape
+        return ops.scatter_dense(self._f, self._i, self._c, (D, H, W), self.batch_size)
+
+
+class Engine:
+    def __init__(self, det, device):
+        self.device = device
+        self.epoch = surgery_epoch()
+        self.det = det
+        ds = det.dataset
+        self.batch_cap = int(getattr(det, "max_batch_size", 1))
+        self.num_point_features = int(ds.point_feature_encoder.num_point_features)
+        self.pc_range = [float(v) for v in ds.point_cloud_range]
+        self.voxel_size = [float(v) for v in ds.voxel_size]
+        self.grid_size = [int(v) for v in ds.grid_size]
+        proc = {c.NAME: c for c in ds.dataset_cfg.DATA_PROCESSOR}
+        vcfg = proc["transform_points_to_voxels"]
+        self.max_points_per_voxel = int(vcfg.MAX_POINTS_PER_VOXEL)
+        self.max_voxels = int(vcfg.MAX_NUMBER_OF_VOXELS["test"])
+        cap_opt = getattr(det, "voxel_capacity", None)
+        self.cap = int(cap_opt) if cap_opt else self.max_voxels * self.batch_cap
+        self.arena = _Arena(device)
+        self.steps = []
+        self.tensors = {}
+        self._voxel_ws = None
+        self._build_sparse(det.backbone_3d)
+        self._build_dense(det.backbone_2d, det.dense_head)
+        self.arena.finalize()
+
+    # ------------------------------------------------------------------ helpers
+    def _dev(self, arr, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(arr))
+        if dtype is not None:
+            t = t.to(dtype)
+        return t.to(self.device)
+
+    # ------------------------------------------------------------------ sparse backbone
+    def _build_sparse(self, bb):
+        dev, cap = self.device, self.cap
+        shape0 = list(bb.sparse_shape)
+        self.levels = []          # dicts: shape, coords, count, table, nbr(subm), cap
+
+        def new_level(shape):
+            lv = dict(shape=list(shape), coords=torch.zeros((cap, 4), dtype=i32, device=dev),
+                      count=torch.zeros((1,), dtype=i32, device=dev), table=ops.HashTable(cap, dev),
+                      nbr=torch.full((cap, 27), -1, dtype=i32, device=dev))
+            self.levels.append(lv)
+            return lv
+
+        lv0 = new_level(shape0)
+        C0 = self.num_point_features
+        self.vfe_feats = torch.zeros((cap, C0), dtype=f32, device=dev)
+        self.vfe_npts = torch.zeros((cap,), dtype=i32, device=dev)
+        self.sparse_convs = []    # compiled conv records (for introspection / tests)
+        self.multi_scale = {}
+
+        def tensor(level, C, name):
+            t = dict(buf=torch.zeros((cap, C), dtype=f32, device=dev), C=C, level=level,
+                     amax=self.arena.alloc(C), name=name)
+            return t
+
+        def compile_conv(mod, path, x, level_out, nbr, kvol, bn, relu, residual=None):
+            """mod: SparseConvolution or QConvNd. Returns output tensor record."""
+            q = mod if isinstance(mod, QConvNd) else None
+            conv = mod.module if q is not None else mod
+            assert isinstance(conv, SparseConvolution)
+            cin, cout = conv.in_channels, conv.out_channels
+            w = _np(conv.weight).reshape(cout, kvol, cin)               # KRSC → [cout, kvol, cin]
+            rec = dict(path=path, cin=cin, cout=cout, kvol=kvol, x=x, nbr=nbr, level=level_out, relu=relu,
+                       residual=residual, quant=None)
+            quant_on = q is not None and q.w_quant._if_quant
+            if quant_on:
+                codes, wdq, _ = quantize_weight_rows(np.moveaxis(w, 2, 1).reshape(cout, -1), q.w_bits)   # [oc, ic*k^3] view
+                codes = np.moveaxis(codes.reshape(cout, cin, kvol), 1, 2)                               # back to [cout,kvol,cin]
+                if q.w_bits <= 8 and cin % 16 == 0:
+                    rec["weight"] = self._dev(np.transpose(codes, (1, 0, 2)).astype(np.int8))
+                    rec["w_dequant"] = self._dev(wdq)
+                else:   # fake-quantised fp32 weights through the fp32 weight path
+                    wfq = (codes.astype(np.float32) * wdq[:, None, None]).astype(np.float32)
+                    rec["weight"] = self._dev(np.transpose(wfq, (1, 0, 2)))
+                    rec["w_dequant"] = None
+            else:
+                rec["weight"] = self._dev(np.transpose(w, (1, 0, 2)))
+                rec["w_dequant"] = None
+            rec["bias"] = self._dev(_np(conv.bias)) if conv.bias is not None else None
+            if bn is not None:
+                s, b = fold_bn(bn)
+                rec["post_scale"], rec["post_shift"] = self._dev(s), self._dev(b)
+            else:
+                rec["post_scale"] = rec["post_shift"] = None
+            if q is not None:
+                aq = q.act_quant
+                rec["quant"] = dict(bits=q.act_bits, per_tensor=not q.cw, quantizer=aq, on=aq._if_quant,
+                                    calib=aq._if_calib,
+                                    static_amax=None if aq.amax is None else self._dev(_np(aq.amax).reshape(-1)))
+                use_codes = q.act_bits <= 8 and cin % 16 == 0
+                rec["quant"]["use_codes"] = use_codes
+                rec["codes"] = torch.zeros((cap, cin), dtype=torch.int8, device=dev) if use_codes else None
+                rec["fq"] = None if use_codes else torch.zeros((cap, cin), dtype=f32, device=dev)
+                rec["dq"] = torch.zeros((cin,), dtype=f32, device=dev)
+            out = tensor(level_out, cout, path)
+            rec["out"] = out
+            self.sparse_convs.append(rec)
+            self.steps.append(("spconv", rec))
+            return out
+
+        def run_block(blk, path, x, level, nbr):
+            assert isinstance(blk, SparseBasicBlock)
+            t = compile_conv(blk.conv1, path + ".conv1", x, level, nbr, 27, blk.bn1, True)
+            return compile_conv(blk.conv2, path + ".conv2", t, level, nbr, 27, blk.bn2, True, residual=x)
+
+        # level 0: voxels → hash + submanifold gather table (shared by conv_input 'subm1' and conv1 'res1')
+        self.steps.append(("index_subm", 0))
+        x_in = dict(buf=self.vfe_feats, C=C0, level=0, amax=self.arena.alloc(C0), name="vfe")
+        self.steps.append(("absmax", x_in))      # only consumed if conv_input is quantised (sq=False recipe)
+        ci = bb.conv_input
+        x = compile_conv(ci[0], "backbone_3d.conv_input.0", x_in, 0, 0, 27, ci[1], True)
+        for bi, blk in enumerate(bb.conv1):
+            x = run_block(blk, "backbone_3d.conv1.%d" % bi, x, 0, 0)
+        self.multi_scale["x_conv1"] = (x, 0)
+        for si, name in enumerate(("conv2", "conv3", "conv4")):
+            stage = getattr(bb, name)
+            down = stage[0]
+            conv = down[0].module if isinstance(down[0], QConvNd) else down[0]
+            lv_in = self.levels[si]
+            lv_out = new_level(ops.conv_out_shape(lv_in["shape"], conv.kernel_size, conv.stride, conv.padding))
+            lv_out["down"] = dict(ksize=conv.kernel_size, stride=conv.stride, pad=conv.padding,
+                                  nbr=torch.full((cap, 27), -1, dtype=i32, device=dev))
+            self.steps.append(("index_down", si + 1))
+            x = compile_conv(down[0], "backbone_3d.%s.0.0" % name, x, si + 1, ("down", si + 1), 27, down[1], True)
+            self.steps.append(("index_subm", si + 1))
+            for bi in range(1, len(stage)):
+                x = run_block(stage[bi], "backbone_3d.%s.%d" % (name, bi), x, si + 1, si + 1)
+            self.multi_scale["x_%s" % name] = (x, si + 1)
+        co = bb.conv_out
+        conv = co[0].module if isinstance(co[0], QConvNd) else co[0]
+        lv_in = self.levels[3]
+        lv_out = new_level(ops.conv_out_shape(lv_in["shape"], conv.kernel_size, conv.stride, conv.padding))
+        kvol = int(np.prod(conv.kernel_size))
+        lv_out["down"] = dict(ksize=conv.kernel_size, stride=conv.stride, pad=conv.padding,
+                              nbr=torch.full((cap, kvol), -1, dtype=i32, device=dev))
+        self.steps.append(("index_down", 4))
+        x = compile_conv(co[0], "backbone_3d.conv_out.0", x, 4, ("down", 4), kvol, co[1], True)
+        self.encoded = (x, 4)
+        need = max(ops._lib.load().aq3d_conv_outputs_workspace_bytes(cap, 27, self.levels[0]["table"].size), 256)
+        self.index_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+
+    # ------------------------------------------------------------------ dense BEV backbone + head
+    def _build_dense(self, b2d, head):
+        dev, B = self.device, self.batch_cap
+        D, H, W = self.levels[4]["shape"]
+        Cenc = self.encoded[0]["C"]
+        self.bev_shape = (D, H, W)
+        self.spatial = torch.zeros((B, H, W, Cenc * D), dtype=f32, device=dev)
+        self.steps.append(("scatter_dense", None))
+        self.dense_convs = []
+
+        def compile_conv2d(mod, path, x, xH, xW, x_ld, pad_extra, bn, relu, out=None, out_ld=None, out_coff=0):
+            """mod: nn.Conv2d | SQConv2d | QuantConv2d | nn.ConvTranspose2d. x: [B, xH, xW, x_ld] buffer."""
+            rec = dict(path=path, x=x, quant=None)
+            if isinstance(mod, nn.ConvTranspose2d):
+                d = mod.stride[0]
+                assert mod.kernel_size[0] == d and mod.padding[0] == 0, "only kernel == stride transposed convs"
+                cin, cout = mod.in_channels, mod.out_channels
+                g = ops.conv_geom(xH, xW, cin, cout, 1, 1, 0, in_ld=x_ld, out_ld=out_ld or cout, out_coff=out_coff,
+                                  deconv=d, relu=relu)
+                rec["weight"] = ops.deconv_weight_to_k(mod.weight.detach().float()).to(dev)
+                Ho, Wo = xH * d, xW * d
+                rec["kind"] = "f32"
+            else:
+                k = mod.kernel_size if isinstance(mod.kernel_size, int) else mod.kernel_size[0]
+                s = mod.stride if isinstance(mod.stride, int) else mod.stride[0]
+                p = (mod.padding if isinstance(mod.padding, int) else mod.padding[0]) + pad_extra
+                cin, cout = mod.in_channels, mod.out_channels
+                g = ops.conv_geom(xH, xW, cin, cout, k, s, p, in_ld=x_ld, out_ld=out_ld or cout, out_coff=out_coff,
+                                  relu=relu)
+                Ho, Wo = g.Ho, g.Wo
+                wk = ops.conv_weight_to_k(mod.weight.detach().float())
+                is_q = isinstance(mod, _QuantConv2dBase) and mod._input_quantizer._if_quant
+                if is_q and (cin % 64 != 0 or mod._weight_quantizer.num_bits > 8 or mod._input_quantizer.num_bits > 8):
+                    raise NotImplementedError("int8 dense conv needs Cin %% 64 == 0 and <= 8 bits (%s)" % path)
+                if is_q:
+                    cpad = (cout + 3) // 4 * 4
+                    if cpad != cout:    # pad the output channels to the 16-byte store granularity
+                        wk = torch.cat([wk, torch.zeros((cpad - cout, wk.shape[1]))], 0)
+                        g.Cout = cpad
+                    rec["kind"] = "i8"
+                    rec["weight"] = wk.contiguous().to(dev)
+                    rec["w_colmax"] = rec["weight"].abs().max(dim=0)[0].contiguous()
+                    rec["alpha"] = mod.scaling_factor
+                    rec["pieces"] = self.arena.alloc(16 * cin)
+                    rec["params"] = torch.empty((ops.sq_param_bytes(cin, g.Cout, k),), dtype=torch.uint8, device=dev)
+                    wq_, iq_ = mod._weight_quantizer, mod._input_quantizer
+                    rec["w_bits"], rec["a_bits"] = wq_.num_bits, iq_.num_bits
+                    rec["static_x"] = float(iq_.amax.reshape(-1)[0]) if iq_.amax is not None else 0.0
+                    sw = None
+                    if wq_.amax is not None:
+                        sw = torch.zeros((g.Cout,), dtype=f32)
+                        sw[:cout] = wq_.amax.reshape(-1)
+                        sw = sw.to(dev)
+                    rec["static_w"] = sw
+                    rec["quantizers"] = (wq_, iq_)
+                else:
+                    rec["kind"] = "f32"
+                    rec["weight"] = wk.contiguous().to(dev)
+                    if isinstance(mod, _QuantConv2dBase) and (mod._input_quantizer._if_calib or mod._weight_quantizer._if_calib):
+                        # calibration pass: run in fp32, harvest the amax the quantised layer would see
+                        rec["calib"] = dict(pieces=self.arena.alloc(16 * cin), alpha=mod.scaling_factor,
+                                            w_colmax=rec["weight"].abs().max(dim=0)[0].contiguous(),
+                                            params=torch.empty((ops.sq_param_bytes(cin, (cout + 3) // 4 * 4, k),),
+                                                               dtype=torch.uint8, device=dev),
+                                            quantizers=(mod._weight_quantizer, mod._input_quantizer), k=k, cout=cout)
+            bias = getattr(mod, "bias", None)
+            cfull = g.Cout
+            def padv(v, fill):
+                v = np.asarray(v, dtype=np.float32)
+                if len(v) < cfull:
+                    v = np.concatenate([v, np.full((cfull - len(v),), fill, np.float32)])
+                return self._dev(v)
+            rec["bias"] = padv(_np(bias), 0.0) if bias is not None else None
+            if bn is not None:
+                s_, b_ = fold_bn(bn)
+                rec["post_scale"], rec["post_shift"] = padv(s_, 1.0), padv(b_, 0.0)
+            else:
+                rec["post_scale"] = rec["post_shift"] = None
+            rec["geom"] = g
+            if out is None:
+                out = torch.zeros((B, Ho, Wo, out_ld or g.Cout), dtype=f32, device=dev)
+            rec["out"] = out
+            rec["out_hw"] = (Ho, Wo)
+            self.dense_convs.append(rec)
+            self.steps.append(("conv2d", rec))
+            return out, Ho, Wo
+
+        def run_sequential(seq, path, x, xH, xW, x_ld, out=None, out_ld=None, out_coff=0):
+            """nn.Sequential of [ZeroPad2d] Conv/Deconv [BN] [ReLU] groups (base_bev_backbone.py:30-66)."""
+            mods = list(seq.named_children())
+            i, pad_extra = 0, 0
+            convs = []
+            while i < len(mods):
+                name, m = mods[i]
+                if isinstance(m, nn.ZeroPad2d):
+                    pad_extra = int(m.padding[0])
+                    i += 1
+                    continue
+                if isinstance(m, nn.Sequential):        # nested conv-bn-relu group (head branches)
+                    convs.append((path + "." + name, m, None))
+                    i += 1
+                    continue
+                assert isinstance(m, (nn.Conv2d, nn.ConvTranspose2d, _QuantConv2dBase)), (path, name, type(m))
+                bn, relu, j = None, False, i + 1
+                if j < len(mods) and isinstance(mods[j][1], nn.BatchNorm2d):
+                    bn, j = mods[j][1], j + 1
+                if j < len(mods) and isinstance(mods[j][1], nn.ReLU):
+                    relu, j = True, j + 1
+                convs.append((path + "." + name, m, (bn, relu, pad_extra)))
+                pad_extra = 0
+                i = j
+            for ci_, (p_, m, extra) in enumerate(convs):
+                last = ci_ == len(convs) - 1
+                kw = dict(out=out, out_ld=out_ld, out_coff=out_coff) if last else {}
+                if extra is None:
+                    x, xH, xW = run_sequential(m, p_, x, xH, xW, x_ld, **kw)
+                else:
+                    bn, relu, pe = extra
+                    x, xH, xW = compile_conv2d(m, p_, x, xH, xW, x_ld, pe, bn, relu, **kw)
+                x_ld = x.shape[-1]
+            return x, xH, xW
+
+        ups_c = [int(c) for c in (b2d.model_cfg.get("NUM_UPSAMPLE_FILTERS", None) or [])]
+        x, xH, xW, x_ld = self.spatial, H, W, Cenc * D
+        self.bev_cat = None
+        coff = 0
+        for bi, blk in enumerate(b2d.blocks):
+            x, xH, xW = run_sequential(blk, "backbone_2d.blocks.%d" % bi, x, xH, xW, x_ld)
+            x_ld = x.shape[-1]
+            if len(b2d.deblocks) > 0:
+                de = b2d.deblocks[bi]
+                first = de[0]
+                d = first.stride[0] if isinstance(first, nn.ConvTranspose2d) else 1
+                if self.bev_cat is None:
+                    self.bev_cat = torch.zeros((B, xH * d, xW * d, sum(ups_c)), dtype=f32, device=dev)
+                run_sequential(de, "backbone_2d.deblocks.%d" % bi, x, xH, xW, x_ld, out=self.bev_cat,
+                               out_ld=sum(ups_c), out_coff=coff)
+                coff += ups_c[bi]
+        if self.bev_cat is None:
+            self.bev_cat = x
+        catH, catW, cat_ld = self.bev_cat.shape[1], self.bev_cat.shape[2], self.bev_cat.shape[3]
+        sh, sH, sW = run_sequential(head.shared_conv, "dense_head.shared_conv", self.bev_cat, catH, catW, cat_ld)
+        self.head_hw = (sH, sW)
+        # head outputs: one [B, L, 24] buffer per head, 4-aligned slots per branch
+        slots = {"hm": 0, "center": 4, "center_z": 8, "dim": 12, "rot": 16, "vel": 20}
+        self.HEAD_LD = 24
+        pp = head.model_cfg.POST_PROCESSING
+        K = int(pp.MAX_OBJ_PER_SAMPLE)
+        nms = pp.NMS_CONFIG
+        assert nms.NMS_TYPE == "nms_gpu", "only class-agnostic rotated NMS (nms_gpu) is on the CenterPoint path"
+        self.heads = []
+        for hi, sep in enumerate(head.heads_list):
+            hbuf = torch.zeros((B, sH, sW, self.HEAD_LD), dtype=f32, device=dev)
+            for name in sep.sep_head_dict:
+                assert name in slots, "unsupported head branch %s" % name
+                run_sequential(getattr(sep, name), "dense_head.heads_list.%d.%s" % (hi, name), sh, sH, sW, sh.shape[-1],
+                               out=hbuf, out_ld=self.HEAD_LD, out_coff=slots[name])
+            ncls = len(head.class_names_each_head[hi])
+            has_vel = "vel" in sep.sep_head_dict
+            cfg = ops.make_decode_cfg(sH, sW, ncls, K, has_vel, head.feature_map_stride, self.voxel_size[:2],
+                                      self.pc_range[:2], [float(v) for v in pp.POST_CENTER_LIMIT_RANGE],
+                                      pp.SCORE_THRESH, self.HEAD_LD, self.HEAD_LD)
+            nb = 9 if has_vel else 7
+            L_ = ops._lib.load()
+            import ctypes
+            rec = dict(buf=hbuf, cfg=cfg, slots=slots, has_vel=has_vel, nb=nb, K=K,
+                       thresh=float(nms.NMS_THRESH), pre=int(nms.NMS_PRE_MAXSIZE), post=int(nms.NMS_POST_MAXSIZE),
+                       class_map=head.class_id_mapping_each_head[hi].to(dev).to(i32).contiguous(),
+                       cand_boxes=torch.zeros((B, K, nb), dtype=f32, device=dev),
+                       cand_scores=torch.zeros((B, K), dtype=f32, device=dev),
+                       cand_labels=torch.zeros((B, K), dtype=i32, device=dev),
+                       cand_count=torch.zeros((B, 1), dtype=i32, device=dev),
+                       keep=torch.zeros((B, K), dtype=i32, device=dev),
+                       out_boxes=torch.zeros((B, K, nb), dtype=f32, device=dev),
+                       out_scores=torch.zeros((B, K), dtype=f32, device=dev),
+                       out_labels=torch.zeros((B, K), dtype=torch.int64, device=dev),
+                       dec_ws=torch.empty((max(L_.aq3d_center_decode_workspace_bytes(ctypes.byref(cfg)), 256),),
+                                          dtype=torch.uint8, device=dev),
+                       nms_ws=torch.empty((max(L_.aq3d_nms_workspace_bytes(K), 256),), dtype=torch.uint8, device=dev))
+            self.heads.append(rec)
+        self.det_counts = torch.zeros((B, len(self.heads)), dtype=i32, device=dev)
+        self.steps.append(("decode_nms", None))
+
+    # ------------------------------------------------------------------ execution
+    def _voxelize(self, batch_dict, B):
+        lv0 = self.levels[0]
+        if "voxels" in batch_dict and "voxel_coords" in batch_dict and not getattr(self.det, "voxelize_on_device", False):
+            # pre-voxelized input (pcdet contract: voxels [M,P,C], voxel_num_points [M], voxel_coords [M,4] float)
+            vox = batch_dict["voxels"].to(self.device, f32).contiguous()
+            m = vox.shape[0]
+            if m > self.cap:
+                raise ValueError("batch has %d voxels, engine capacity is %d" % (m, self.cap))
+            if m > 0:
+                self.vfe_feats[:m] = ops.mean_vfe(vox, batch_dict["voxel_num_points"].to(self.device))
+                lv0["coords"][:m] = batch_dict["voxel_coords"].to(self.device).to(i32)
+            lv0["count"].fill_(m)
+            return
+        pts = batch_dict["points"]
+        assert pts.is_cuda, "points must be on the device (load_data_to_gpu)"
+        stride = pts.shape[1]
+        has_b = stride == self.num_point_features + 1
+        cfg = ops.make_voxel_cfg(self.pc_range, self.voxel_size, self.grid_size, self.num_point_features, stride, has_b,
+                                 self.max_points_per_voxel, self.max_voxels)
+        out = (lv0["coords"], self.vfe_feats, self.vfe_npts, lv0["count"])
+        if has_b and B > 1:
+            # samples are contiguous row ranges (collate_batch concatenates in batch order); ranges are host data
+            offs = batch_dict.get("points_batch_offsets", None)
+            if offs is None:
+                bcol = pts[:, 0].to(torch.int64)
+                cnt = torch.bincount(bcol, minlength=B).cpu().tolist()          # one small D2H, batch > 1 only
+                offs = np.concatenate([[0], np.cumsum(cnt)]).tolist()
+            for b in range(B):
+                seg = pts[offs[b]:offs[b + 1]]
+                need = ops._lib.load().aq3d_voxelize_workspace_bytes(max(seg.shape[0], 1))
+                if self._voxel_ws is None or self._voxel_ws.numel() < need:
+                    self._voxel_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+                ops.voxelize(seg, cfg, self.cap, batch_index=b, append=b > 0, out=out, workspace=self._voxel_ws)
+        else:
+            need = ops._lib.load().aq3d_voxelize_workspace_bytes(max(pts.shape[0], 1))
+            if self._voxel_ws is None or self._voxel_ws.numel() < need:
+                self._voxel_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+            ops.voxelize(pts, cfg, self.cap, batch_index=0, append=False, out=out, workspace=self._voxel_ws)
+
+    def _nbr_of(self, ref):
+        if isinstance(ref, tuple):
+            return self.levels[ref[1]]["down"]["nbr"]
+        return self.levels[ref]["nbr"]
+
+    def _run_spconv(self, rec):
+        lv = self.levels[rec["level"]]
+        x = rec["x"]
+        nbr = self._nbr_of(rec["nbr"])
+        in_count = self.levels[x["level"]]["count"]
+        feats, act_dq = x["buf"], None
+        q = rec["quant"]
+        if q is not None and q["calib"]:
+            amax = self.arena.view(x["amax"])
+            q["quantizer"].collect(amax.max().reshape(1) if q["per_tensor"] else amax)
+        if q is not None and q["on"]:
+            amax = q["static_amax"] if q["static_amax"] is not None else self.arena.view(x["amax"])
+            if q["static_amax"] is not None and q["static_amax"].numel() == 1 and x["C"] > 1:
+                amax = q["static_amax"].expand(x["C"]).contiguous()
+            L = ops._lib.load()
+            ops.check(L.aq3d_quantize_rows(ops._p(x["buf"]), ops._p(amax), ops._p(in_count), self.cap, x["C"], q["bits"],
+                                           int(q["per_tensor"]), ops._p(rec["codes"]), ops._p(rec["fq"]), ops._p(rec["dq"]),
+                                           ops._stream()), "aq3d_quantize_rows")
+            if q["use_codes"]:
+                feats, act_dq = rec["codes"], rec["dq"]
+            else:
+                feats = rec["fq"]
+        out = rec["out"]
+        ops.spconv(feats, rec["weight"], nbr, lv["count"], rec["cout"], act_dequant=act_dq, w_dequant=rec["w_dequant"],
+                   bias=rec["bias"], post_scale=rec["post_scale"], post_shift=rec["post_shift"],
+                   residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
+                   absmax_out=self.arena.view(out["amax"]), out=out["buf"])
+
+    def _run_conv2d(self, rec, B):
+        g = rec["geom"]
+        x, out = rec["x"], rec["out"]
+        if rec["kind"] == "i8":
+            pieces = self.arena.view(rec["pieces"], (16, g.Cin))
+            for b in range(B):
+                ops.piece_absmax(x[b], g.H, g.W, g.Cin, g.in_ld, pieces)
+            ops.sq_prep(pieces, rec["weight"], rec["w_colmax"], g, rec["alpha"], rec["params"], rec["w_bits"],
+                        rec["a_bits"], rec["static_x"], rec["static_w"])
+            for b in range(B):
+                ops.conv2d_i8(x[b], rec["params"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b])
+        else:
+            cal = rec.get("calib")
+            if cal is not None:
+                self._harvest_calib(rec, cal, B)
+            for b in range(B):
+                ops.conv2d_f32(x[b], rec["weight"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b])
+
+    def _harvest_calib(self, rec, cal, B):
+        """Calibration forward of an SQConv2d/QuantConv2d: the amax its two quantizers would see this batch."""
+        g = rec["geom"]
+        pieces = self.arena.view(cal["pieces"], (16, g.Cin))
+        for b in range(B):
+            ops.piece_absmax(rec["x"][b], g.H, g.W, g.Cin, g.in_ld, pieces)
+        cout4 = (cal["cout"] + 3) // 4 * 4
+        g2 = ops.conv_geom(g.H, g.W, g.Cin, cout4, g.ksize, g.stride, g.pad, in_ld=g.in_ld)
+        wk = rec["weight"]
+        if wk.shape[0] < cout4:
+            wk = torch.cat([wk, torch.zeros((cout4 - wk.shape[0], wk.shape[1]), device=wk.device)], 0).contiguous()
+        ops.sq_prep(pieces, wk, cal["w_colmax"], g2, cal["alpha"], cal["params"])
+        v = ops.sq_param_views(cal["params"], g.Cin, cout4, g.ksize)
+        scal, amax_w = v["scal"], v["amax_w"][:cal["cout"]]
+        wq_, iq_ = cal["quantizers"]
+        if iq_._if_calib:
+            iq_.collect(scal[1:2])
+        if wq_._if_calib:
+            wq_.collect(amax_w)
+
+    def _decode_nms(self, B):
+        for hi, h in enumerate(self.heads):
+            s = h["slots"]
+            for b in range(B):
+                buf = h["buf"][b].view(-1, self.HEAD_LD)
+                ops.center_decode(buf[:, s["hm"]:], buf[:, s["center"]:], buf[:, s["center_z"]:], buf[:, s["dim"]:],
+                                  buf[:, s["rot"]:], buf[:, s["vel"]:] if h["has_vel"] else None, h["cfg"],
+                                  workspace=h["dec_ws"],
+                                  out=(h["cand_boxes"][b], h["cand_scores"][b], h["cand_labels"][b], h["cand_count"][b]))
+                cap_nms = min(h["K"], h["pre"])
+                ops.nms_rotated(h["cand_boxes"][b][:cap_nms], h["cand_count"][b], h["thresh"], h["post"],
+                                workspace=h["nms_ws"], out=(h["keep"][b][:cap_nms], self.det_counts[b, hi:hi + 1]))
+                ops.gather_dets(h["cand_boxes"][b][:cap_nms], h["cand_scores"][b][:cap_nms], h["cand_labels"][b][:cap_nms],
+                                h["class_map"], h["keep"][b][:cap_nms], self.det_counts[b, hi:hi + 1],
+                                out=(h["out_boxes"][b][:cap_nms], h["out_scores"][b][:cap_nms], h["out_labels"][b][:cap_nms]))
+
+    def run(self, batch_dict):
+        """Enqueue one batch. Returns nothing; results sit in self.heads[*]['out_*'] and self.det_counts."""
+        B = int(batch_dict["batch_size"])
+        if B > self.batch_cap:
+            raise ValueError("batch_size %d exceeds the engine's max_batch_size %d" % (B, self.batch_cap))
+        self.arena.clear()
+        self._voxelize(batch_dict, B)
+        for kind, arg in self.steps:
+            if kind == "spconv":
+                self._run_spconv(arg)
+            elif kind == "conv2d":
+                self._run_conv2d(arg, B)
+            elif kind == "index_subm":
+                lv = self.levels[arg]
+                if "down" not in lv:       # level 0: table from the voxel coords; deeper levels get it from conv_outputs
+                    ops.hash_build(lv["coords"], lv["count"], lv["shape"], lv["table"])
+                ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], (3, 3, 3), lv["table"], out=lv["nbr"])
+            elif kind == "index_down":
+                self._index_down(arg)
+            elif kind == "absmax":
+                if any(r["quant"] is not None and (r["quant"]["on"] or r["quant"]["calib"]) and r["x"] is arg
+                       for r in self.sparse_convs):
+                    ops.absmax_cols(arg["buf"], self.levels[arg["level"]]["count"], self.arena.view(arg["amax"]))
+            elif kind == "scatter_dense":
+                x, lvl = self.encoded
+                lv = self.levels[lvl]
+                ops.scatter_dense(x["buf"], lv["coords"], lv["count"], self.bev_shape, B, out=self.spatial[:B])
+            elif kind == "decode_nms":
+                self._decode_nms(B)
+        return B
+
+    def _index_down(self, li):
+        lv_in, lv_out = self.levels[li - 1], self.levels[li]
+        d = lv_out["down"]
+        L = ops._lib.load()
+        kvol = int(np.prod(d["ksize"]))
+        t_in, t_out = lv_in["table"], lv_out["table"]
+        ops.check(L.aq3d_conv_outputs(ops._p(lv_in["coords"]), ops._p(lv_in["count"]), self.cap, ops.I3(*lv_in["shape"]),
+                                      ops.I3(*d["ksize"]), ops.I3(*d["stride"]), ops.I3(*d["pad"]), ops._p(t_in.keys),
+                                      ops._p(t_in.vals), t_in.size, ops._p(lv_out["coords"]), ops._p(lv_out["count"]),
+                                      self.cap, ops._p(d["nbr"]), ops._p(t_out.keys), ops._p(t_out.vals), t_out.size,
+                                      ops._p(self.index_ws), self.index_ws.numel(), ops._stream()), "aq3d_conv_outputs")
+
+    # ------------------------------------------------------------------ results
+    def collect(self, B):
+        """One device→host read (the detection counts), then slice the padded outputs into pred_dicts."""
+        counts = self.det_counts[:B].cpu().numpy()
+        preds = []
+        for b in range(B):
+            bx, sc, lb = [], [], []
+            for hi, h in enumerate(self.heads):
+                n = int(counts[b, hi])
+                bx.append(h["out_boxes"][b, :n])
+                sc.append(h["out_scores"][b, :n])
+                lb.append(h["out_labels"][b, :n])
+            if len(self.heads) == 1:
+                preds.append({"pred_boxes": bx[0].clone(), "pred_scores": sc[0].clone(), "pred_labels": lb[0].clone()})
+            else:
+                nbmax = max(t.shape[1] for t in bx)
+                bx = [t if t.shape[1] == nbmax else torch.cat([t, t.new_zeros((t.shape[0], nbmax - t.shape[1]))], 1) for t in bx]
+                preds.append({"pred_boxes": torch.cat(bx, 0), "pred_scores": torch.cat(sc, 0), "pred_labels": torch.cat(lb, 0)})
+        return preds
+
+    def sparse_view(self, name):
+        """'x_conv1'..'x_conv4' or 'encoded' → SparseTensorView over the live rows (host sync on access)."""
+        x, lvl = self.encoded if name == "encoded" else self.multi_scale[name]
+        lv = self.levels[lvl]
+        return SparseTensorView(x["buf"], lv["coords"], lv["count"], lv["shape"], self.batch_cap)

@@ -23,6 +23,14 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+def _pv(t):
+    """pointer of a (possibly strided) view; the caller passes the pixel stride separately"""
+    if t is None:
+        return None
+    assert t.is_cuda, "aq3d ops take device tensors (no CPU fallback)"
+    return ctypes.c_void_p(t.data_ptr())
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -297,7 +305,7 @@ def center_decode(hm, center, center_z, dim, rot, vel, cfg, workspace=None, out=
     need = L.aq3d_center_decode_workspace_bytes(ctypes.byref(cfg))
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
-    check(L.aq3d_center_decode(_p(hm), _p(center), _p(center_z), _p(dim), _p(rot), _p(vel), ctypes.byref(cfg), _p(boxes),
+    check(L.aq3d_center_decode(_pv(hm), _pv(center), _pv(center_z), _pv(dim), _pv(rot), _pv(vel), ctypes.byref(cfg), _p(boxes),
                                _p(scores), _p(labels), _p(count), _p(workspace), workspace.numel(), _stream()),
           "aq3d_center_decode")
     return boxes, scores, labels, count
@@ -335,3 +343,22 @@ def gather_dets(boxes, scores, labels, class_map, keep, keep_count, out=None):
     check(L.aq3d_gather_dets(_p(boxes), ld, _p(scores), _p(labels), _p(class_map), _p(keep), _p(keep_count), cap, _p(bo),
                              _p(so), _p(lo), _stream()), "aq3d_gather_dets")
     return bo, so, lo
+
+
+def sq_param_views(params, Cin, Cout, ksize):
+    """Views into a parameter block written by sq_prep (layout of csrc/sq_layout.h)."""
+    K = Cin * ksize * ksize
+    al = lambda v: (v + 255) // 256 * 256
+    o_r = al(K * 4)
+    o_mul = o_r + al(K * 4)
+    o_amaxw = o_mul + al(Cout * 4)
+    o_scal = o_amaxw + al(Cout * 4)
+    o_wq = o_scal + 256
+    return {
+        "s": params[0:K * 4].view(f32),
+        "rinv": params[o_r:o_r + K * 4].view(f32),
+        "out_mul": params[o_mul:o_mul + Cout * 4].view(f32),
+        "amax_w": params[o_amaxw:o_amaxw + Cout * 4].view(f32),
+        "scal": params[o_scal:o_scal + 32].view(f32),     # [sx, amax_x, 1/sx, ...]
+        "wq": params[o_wq:o_wq + Cout * K].view(torch.int8).view(Cout, K),
+    }

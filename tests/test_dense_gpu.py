@@ -72,8 +72,7 @@ def test_conv2d_i8_vs_sqconv2d(dev, Cin, Cout, H, W, stride, alpha, use_bias, us
     y = ops.conv2d_i8(xg, params, geom, bias=None if bias is None else bias.to(dev),
                       post_scale=None if ps is None else ps.to(dev), post_shift=None if pt is None else pt.to(dev))
     y = y.cpu().permute(2, 0, 1)[None]
-    K = 9 * Cin
-    amax_x = params.cpu()[2 * ((K * 4 + 255) // 256 * 256) + ((Cout * 4 + 255) // 256 * 256):][:8].view(torch.float32)[1].item()
+    amax_x = ops.sq_param_views(params, Cin, Cout, 3)["scal"][1].item()
     assert amax_x == pytest.approx(float(st["amax_x"]), rel=1e-6)
     tol = 2e-5 * max(1.0, float(ref.abs().max()))
     assert float((y - ref).abs().max()) <= tol
@@ -131,7 +130,7 @@ def _head_maps(H, W, ncls, seed, peaks=300):
     hm = rng.normal(-4.0, 1.0, (ncls, H, W)).astype(np.float32)
     for _ in range(peaks):
         hm[rng.integers(0, ncls), rng.integers(0, H), rng.integers(0, W)] = rng.uniform(-1.0, 4.0)
-    hm[0, 3, 5] = hm[1, 7, 9] = hm[0, 11, 2] = 2.5            # exact score ties (across classes and inside one)
+    hm[0, 3, 5] = hm[ncls - 1, 7, 9] = hm[0, 11, 2] = 2.5            # exact score ties (across classes and inside one)
     center = rng.uniform(0, 1, (2, H, W)).astype(np.float32)
     center_z = rng.uniform(-1.5, 3.5, (1, H, W)).astype(np.float32)
     dim = rng.normal(0.5, 0.4, (3, H, W)).astype(np.float32)
