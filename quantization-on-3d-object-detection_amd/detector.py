@@ -1,0 +1,241 @@
+"""Detector surface of the reference kept as the drop-in boundary:
+
+    Detector3DTemplate            pcdet/models/detectors/detector3d_template.py:14-384
+    CenterPoint                   pcdet/models/detectors/centerpoint.py:4-50
+    build_network / build_detector  pcdet/models/__init__.py:16-20, pcdet/models/detectors/__init__.py
+
+`model(batch_dict)` returns `(pred_dicts, recall_dict)` exactly like the reference in eval mode; the modules are
+parameter containers and the forward runs the HIP engine. There is no CPU / torch fallback: without a GPU and the
+built extension the forward raises.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from . import modules as M
+from .engine import Engine
+from .quant import surgery_epoch
+
+VFE = {"MeanVFE": M.MeanVFE}
+BACKBONE_3D = {"VoxelResBackBone8x": M.VoxelResBackBone8x}
+MAP_TO_BEV = {"HeightCompression": M.HeightCompression}
+BACKBONE_2D = {"BaseBEVBackbone": M.BaseBEVBackbone}
+DENSE_HEAD = {"CenterHead": M.CenterHead}
+
+
+class Detector3DTemplate(nn.Module):
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.dataset = dataset
+        self.class_names = dataset.class_names
+        self.register_buffer("global_step", torch.LongTensor(1).zero_())
+        self.module_topology = ["vfe", "backbone_3d", "map_to_bev_module", "pfe", "backbone_2d", "dense_head",
+                                "point_head", "roi_head"]
+        self._engine = None
+        self.max_batch_size = 1          # engine buffers are sized for this many frames per forward
+        self.voxel_capacity = None       # rows of the sparse buffers (default MAX_NUMBER_OF_VOXELS * max_batch_size)
+        self.voxelize_on_device = True   # False: consume batch_dict['voxels'/'voxel_coords'] when present
+
+    @property
+    def mode(self):
+        return "TRAIN" if self.training else "TEST"
+
+    def update_global_step(self):
+        self.global_step += 1
+
+    def build_networks(self):
+        info = {
+            "module_list": [],
+            "num_rawpoint_features": self.dataset.point_feature_encoder.num_point_features,
+            "num_point_features": self.dataset.point_feature_encoder.num_point_features,
+            "grid_size": self.dataset.grid_size,
+            "point_cloud_range": self.dataset.point_cloud_range,
+            "voxel_size": self.dataset.voxel_size,
+            "depth_downsample_factor": getattr(self.dataset, "depth_downsample_factor", None),
+        }
+        for module_name in self.module_topology:
+            module, info = getattr(self, "build_%s" % module_name)(model_info_dict=info)
+            self.add_module(module_name, module)
+        return info["module_list"]
+
+    def build_vfe(self, model_info_dict):
+        if self.model_cfg.get("VFE", None) is None:
+            return None, model_info_dict
+        m = VFE[self.model_cfg.VFE.NAME](model_cfg=self.model_cfg.VFE,
+                                          num_point_features=model_info_dict["num_rawpoint_features"],
+                                          point_cloud_range=model_info_dict["point_cloud_range"],
+                                          voxel_size=model_info_dict["voxel_size"], grid_size=model_info_dict["grid_size"])
+        model_info_dict["num_point_features"] = m.get_output_feature_dim()
+        model_info_dict["module_list"].append(m)
+        return m, model_info_dict
+
+    def build_backbone_3d(self, model_info_dict):
+        if self.model_cfg.get("BACKBONE_3D", None) is None:
+            return None, model_info_dict
+        m = BACKBONE_3D[self.model_cfg.BACKBONE_3D.NAME](
+            model_cfg=self.model_cfg.BACKBONE_3D, input_channels=model_info_dict["num_point_features"],
+            grid_size=model_info_dict["grid_size"], voxel_size=model_info_dict["voxel_size"],
+            point_cloud_range=model_info_dict["point_cloud_range"])
+        model_info_dict["module_list"].append(m)
+        model_info_dict["num_point_features"] = m.num_point_features
+        model_info_dict["backbone_channels"] = getattr(m, "backbone_channels", None)
+        return m, model_info_dict
+
+    def build_map_to_bev_module(self, model_info_dict):
+        if self.model_cfg.get("MAP_TO_BEV", None) is None:
+            return None, model_info_dict
+        m = MAP_TO_BEV[self.model_cfg.MAP_TO_BEV.NAME](model_cfg=self.model_cfg.MAP_TO_BEV,
+                                                        grid_size=model_info_dict["grid_size"])
+        model_info_dict["module_list"].append(m)
+        model_info_dict["num_bev_features"] = m.num_bev_features
+        return m, model_info_dict
+
+    def build_pfe(self, model_info_dict):
+        assert self.model_cfg.get("PFE", None) is None, "PFE is outside the CenterPoint hot path"
+        return None, model_info_dict
+
+    def build_backbone_2d(self, model_info_dict):
+        if self.model_cfg.get("BACKBONE_2D", None) is None:
+            return None, model_info_dict
+        m = BACKBONE_2D[self.model_cfg.BACKBONE_2D.NAME](model_cfg=self.model_cfg.BACKBONE_2D,
+                                                          input_channels=model_info_dict.get("num_bev_features", None))
+        model_info_dict["module_list"].append(m)
+        model_info_dict["num_bev_features"] = m.num_bev_features
+        return m, model_info_dict
+
+    def build_dense_head(self, model_info_dict):
+        if self.model_cfg.get("DENSE_HEAD", None) is None:
+            return None, model_info_dict
+        m = DENSE_HEAD[self.model_cfg.DENSE_HEAD.NAME](
+            model_cfg=self.model_cfg.DENSE_HEAD, input_channels=model_info_dict["num_bev_features"],
+            num_class=self.num_class if not self.model_cfg.DENSE_HEAD.CLASS_AGNOSTIC else 1, class_names=self.class_names,
+            grid_size=model_info_dict["grid_size"], point_cloud_range=model_info_dict["point_cloud_range"],
+            predict_boxes_when_training=self.model_cfg.get("ROI_HEAD", False),
+            voxel_size=model_info_dict.get("voxel_size", False))
+        model_info_dict["module_list"].append(m)
+        return m, model_info_dict
+
+    def build_point_head(self, model_info_dict):
+        assert self.model_cfg.get("POINT_HEAD", None) is None, "POINT_HEAD is outside the CenterPoint hot path"
+        return None, model_info_dict
+
+    def build_roi_head(self, model_info_dict):
+        assert self.model_cfg.get("ROI_HEAD", None) is None, "ROI_HEAD is outside the CenterPoint hot path"
+        return None, model_info_dict
+
+    # ------------------------------------------------------------------ checkpoints (detector3d_template.py:330-384)
+    def _load_state_dict(self, model_state_disk, *, strict=True):
+        state_dict = self.state_dict()
+        spconv_keys = M.find_all_spconv_keys(self)
+        update_model_state = {}
+        for key, val in model_state_disk.items():
+            if key in spconv_keys and key in state_dict and state_dict[key].shape != val.shape:
+                # spconv 1.x stores (k1, k2, k3, c_in, c_out); adapt to (k1,k2,k3,c_out,c_in) or KRSC (c_out,k1,k2,k3,c_in)
+                val_native = val.transpose(-1, -2)
+                if val_native.shape == state_dict[key].shape:
+                    val = val_native.contiguous()
+                else:
+                    assert val.shape.__len__() == 5, "currently only spconv 3D is supported"
+                    val_implicit = val.permute(4, 0, 1, 2, 3)
+                    if val_implicit.shape == state_dict[key].shape:
+                        val = val_implicit.contiguous()
+            if key in state_dict and state_dict[key].shape == val.shape:
+                update_model_state[key] = val
+        if strict:
+            self.load_state_dict(update_model_state)
+        else:
+            state_dict.update(update_model_state)
+            self.load_state_dict(state_dict)
+        self._engine = None
+        return state_dict, update_model_state
+
+    def load_params_from_file(self, filename, logger, to_cpu=False, pre_trained_path=None):
+        if not os.path.isfile(filename):
+            raise FileNotFoundError
+        logger.info("==> Loading parameters from checkpoint %s to %s" % (filename, "CPU" if to_cpu else "GPU"))
+        loc_type = torch.device("cpu") if to_cpu else None
+        checkpoint = torch.load(filename, map_location=loc_type, weights_only=False)
+        model_state_disk = checkpoint["model_state"]
+        if pre_trained_path is not None:
+            pretrain_checkpoint = torch.load(pre_trained_path, map_location=loc_type, weights_only=False)
+            model_state_disk.update(pretrain_checkpoint["model_state"])
+        version = checkpoint.get("version", None)
+        if version is not None:
+            logger.info("==> Checkpoint trained from version: %s" % version)
+        state_dict, update_model_state = self._load_state_dict(model_state_disk, strict=False)
+        for key in state_dict:
+            if key not in update_model_state:
+                logger.info("Not updated weight %s: %s" % (key, str(state_dict[key].shape)))
+        logger.info("==> Done (loaded %d/%d)" % (len(update_model_state), len(state_dict)))
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _device(self):
+        return self.global_step.device
+
+    def engine(self):
+        """The compiled device plan; rebuilt after weight loading, .cuda(), or any quantization surgery."""
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("the detector runs on an MI355X only: call model.cuda() first (no CPU path)")
+        e = self._engine
+        if e is None or e.epoch != surgery_epoch() or e.device != dev or e.batch_cap < self.max_batch_size:
+            self._engine = Engine(self, dev)
+        return self._engine
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+
+class CenterPoint(Detector3DTemplate):
+    def __init__(self, model_cfg, num_class, dataset):
+        super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+        self.module_list = self.build_networks()
+
+    def forward(self, batch_dict):
+        if self.training:
+            raise NotImplementedError("inference-only build: call model.eval() (training is outside the hot path)")
+        B = int(batch_dict["batch_size"])
+        if B > self.max_batch_size:
+            self.max_batch_size = B
+        eng = self.engine()
+        eng.run(batch_dict)
+        batch_dict["final_box_dicts"] = eng.collect(B)
+        return self.post_processing(batch_dict)
+
+    def forward_async(self, batch_dict):
+        """Enqueue a frame without reading anything back; returns the engine (padded outputs + device counts)."""
+        eng = self.engine()
+        eng.run(batch_dict)
+        return eng
+
+    def post_processing(self, batch_dict):
+        post_process_cfg = self.model_cfg.POST_PROCESSING
+        batch_size = batch_dict["batch_size"]
+        final_pred_dict = batch_dict["final_box_dicts"]
+        recall_dict = {}
+        for index in range(batch_size):
+            pred_boxes = final_pred_dict[index]["pred_boxes"]
+            recall_dict = self.generate_recall_record(box_preds=pred_boxes, recall_dict=recall_dict, batch_index=index,
+                                                      data_dict=batch_dict, thresh_list=post_process_cfg.RECALL_THRESH_LIST)
+        return final_pred_dict, recall_dict
+
+    @staticmethod
+    def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
+        if "gt_boxes" not in data_dict:
+            return recall_dict
+        raise NotImplementedError("recall bookkeeping against gt_boxes needs the 3-D IoU kernels (SURVEY.md §8f rank 3)")
+
+
+DETECTORS = {"CenterPoint": CenterPoint}
+
+
+def build_detector(model_cfg, num_class, dataset):
+    return DETECTORS[model_cfg.NAME](model_cfg=model_cfg, num_class=num_class, dataset=dataset)
+
+
+def build_network(model_cfg, num_class, dataset):
+    return build_detector(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
