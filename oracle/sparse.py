@@ -78,15 +78,19 @@ def conv_outputs(indices, shape, ksize, stride, pad):
     return out_idx, np.stack(cols, axis=1).astype(np.int32), oshape
 
 
+ACCUM_DTYPE = np.float32     # tests flip this to float64 to measure the path's sensitivity to summation order
+
+
 def gather_conv(features, weight_krsc, nbr, bias=None):
     """out[m] = sum_k W_k @ features[nbr[m,k]] in fp32; weight KRSC [Cout, kz,ky,kx, Cin]."""
     cout, cin = weight_krsc.shape[0], weight_krsc.shape[-1]
-    w = weight_krsc.reshape(cout, -1, cin).astype(np.float32)      # [Cout, kvol, Cin]
-    out = np.zeros((nbr.shape[0], cout), dtype=np.float32)
+    w = weight_krsc.reshape(cout, -1, cin).astype(ACCUM_DTYPE)      # [Cout, kvol, Cin]
+    out = np.zeros((nbr.shape[0], cout), dtype=ACCUM_DTYPE)
     for k in range(nbr.shape[1]):
         rows = np.nonzero(nbr[:, k] >= 0)[0]
         if rows.size:
-            out[rows] += features[nbr[rows, k]].astype(np.float32) @ w[:, k, :].T
+            out[rows] += features[nbr[rows, k]].astype(ACCUM_DTYPE) @ w[:, k, :].T
+    out = out.astype(np.float32)
     if bias is not None:
         out = out + bias.astype(np.float32)[None, :]
     return out

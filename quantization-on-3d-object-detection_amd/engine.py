@@ -82,9 +82,32 @@ class SparseTensorView:
         return ops.scatter_dense(self._f, self._i, self._c, (D, H, W), self.batch_size)
 
 
+class _Timed:
+    """HIP-event bracket around a group of launches on the current stream (no host sync)."""
+
+    def __init__(self, eng, cat):
+        self.eng, self.cat = eng, cat
+
+    def __enter__(self):
+        t = self.eng.timers
+        if t is not None and (self.eng.timer_filter is None or self.cat in self.eng.timer_filter):
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        else:
+            self.e0 = None
+
+    def __exit__(self, *a):
+        if self.e0 is not None:
+            self.e1.record()
+            self.eng.timers.setdefault(self.cat, []).append((self.e0, self.e1))
+
+
 class Engine:
     def __init__(self, det, device):
         self.device = device
+        self.timers = None          # dict category -> [(event, event)] when event timing is on
+        self.timer_filter = None
         self.epoch = surgery_epoch()
         self.det = det
         ds = det.dataset
@@ -366,6 +389,7 @@ class Engine:
         if self.bev_cat is None:
             self.bev_cat = x
         catH, catW, cat_ld = self.bev_cat.shape[1], self.bev_cat.shape[2], self.bev_cat.shape[3]
+        self.head_first_step = len(self.steps)
         sh, sH, sW = run_sequential(head.shared_conv, "dense_head.shared_conv", self.bev_cat, catH, catW, cat_ld)
         self.head_hw = (sH, sW)
         # head outputs: one [B, L, 24] buffer per head, 4-aligned slots per branch
@@ -448,6 +472,16 @@ class Engine:
                 self._voxel_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
             ops.voxelize(pts, cfg, self.cap, batch_index=0, append=False, out=out, workspace=self._voxel_ws)
 
+    def start_timing(self, categories=None):
+        self.timers, self.timer_filter = {}, (set(categories) if categories else None)
+
+    def stop_timing(self):
+        """→ {category: (n_launch_groups, total_ms)}; synchronises."""
+        torch.cuda.synchronize(self.device)
+        out = {k: (len(v), float(sum(a.elapsed_time(b) for a, b in v))) for k, v in (self.timers or {}).items()}
+        self.timers = None
+        return out
+
     def _nbr_of(self, ref):
         if isinstance(ref, tuple):
             return self.levels[ref[1]]["down"]["nbr"]
@@ -468,36 +502,42 @@ class Engine:
             if q["static_amax"] is not None and q["static_amax"].numel() == 1 and x["C"] > 1:
                 amax = q["static_amax"].expand(x["C"]).contiguous()
             L = ops._lib.load()
-            ops.check(L.aq3d_quantize_rows(ops._p(x["buf"]), ops._p(amax), ops._p(in_count), self.cap, x["C"], q["bits"],
-                                           int(q["per_tensor"]), ops._p(rec["codes"]), ops._p(rec["fq"]), ops._p(rec["dq"]),
-                                           ops._stream()), "aq3d_quantize_rows")
+            with _Timed(self, "quantize_rows"):
+                ops.check(L.aq3d_quantize_rows(ops._p(x["buf"]), ops._p(amax), ops._p(in_count), self.cap, x["C"], q["bits"],
+                                               int(q["per_tensor"]), ops._p(rec["codes"]), ops._p(rec["fq"]), ops._p(rec["dq"]),
+                                               ops._stream()), "aq3d_quantize_rows")
             if q["use_codes"]:
                 feats, act_dq = rec["codes"], rec["dq"]
             else:
                 feats = rec["fq"]
         out = rec["out"]
-        ops.spconv(feats, rec["weight"], nbr, lv["count"], rec["cout"], act_dequant=act_dq, w_dequant=rec["w_dequant"],
-                   bias=rec["bias"], post_scale=rec["post_scale"], post_shift=rec["post_shift"],
-                   residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
-                   absmax_out=self.arena.view(out["amax"]), out=out["buf"])
+        with _Timed(self, "spconv_c%d" % rec["cout"]):
+            ops.spconv(feats, rec["weight"], nbr, lv["count"], rec["cout"], act_dequant=act_dq, w_dequant=rec["w_dequant"],
+                       bias=rec["bias"], post_scale=rec["post_scale"], post_shift=rec["post_shift"],
+                       residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
+                       absmax_out=self.arena.view(out["amax"]), out=out["buf"])
 
     def _run_conv2d(self, rec, B):
         g = rec["geom"]
         x, out = rec["x"], rec["out"]
         if rec["kind"] == "i8":
             pieces = self.arena.view(rec["pieces"], (16, g.Cin))
-            for b in range(B):
-                ops.piece_absmax(x[b], g.H, g.W, g.Cin, g.in_ld, pieces)
-            ops.sq_prep(pieces, rec["weight"], rec["w_colmax"], g, rec["alpha"], rec["params"], rec["w_bits"],
-                        rec["a_bits"], rec["static_x"], rec["static_w"])
-            for b in range(B):
-                ops.conv2d_i8(x[b], rec["params"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b])
+            with _Timed(self, "piece_absmax"):
+                for b in range(B):
+                    ops.piece_absmax(x[b], g.H, g.W, g.Cin, g.in_ld, pieces)
+            with _Timed(self, "sq_prep"):
+                ops.sq_prep(pieces, rec["weight"], rec["w_colmax"], g, rec["alpha"], rec["params"], rec["w_bits"],
+                            rec["a_bits"], rec["static_x"], rec["static_w"])
+            with _Timed(self, "conv2d_i8"):
+                for b in range(B):
+                    ops.conv2d_i8(x[b], rec["params"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b])
         else:
             cal = rec.get("calib")
             if cal is not None:
                 self._harvest_calib(rec, cal, B)
-            for b in range(B):
-                ops.conv2d_f32(x[b], rec["weight"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b])
+            with _Timed(self, "conv2d_f32"):
+                for b in range(B):
+                    ops.conv2d_f32(x[b], rec["weight"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b])
 
     def _harvest_calib(self, rec, cal, B):
         """Calibration forward of an SQConv2d/QuantConv2d: the amax its two quantizers would see this batch."""
@@ -535,25 +575,41 @@ class Engine:
                                 h["class_map"], h["keep"][b][:cap_nms], self.det_counts[b, hi:hi + 1],
                                 out=(h["out_boxes"][b][:cap_nms], h["out_scores"][b][:cap_nms], h["out_labels"][b][:cap_nms]))
 
+    def run_head_from(self, bev_nhwc):
+        """Run only shared conv → head branches → decode → NMS on given BEV features [B, H, W, C] (parity tests feed
+        the oracle's features here so that box-level comparisons are not swamped by upstream rounding cascades)."""
+        B = bev_nhwc.shape[0]
+        self.arena.clear()
+        self.bev_cat[:B].copy_(bev_nhwc)
+        self._run_steps(self.steps[self.head_first_step:], B)
+        return B
+
     def run(self, batch_dict):
         """Enqueue one batch. Returns nothing; results sit in self.heads[*]['out_*'] and self.det_counts."""
         B = int(batch_dict["batch_size"])
         if B > self.batch_cap:
             raise ValueError("batch_size %d exceeds the engine's max_batch_size %d" % (B, self.batch_cap))
         self.arena.clear()
-        self._voxelize(batch_dict, B)
-        for kind, arg in self.steps:
+        with _Timed(self, "voxelize"):
+            self._voxelize(batch_dict, B)
+        self._run_steps(self.steps, B)
+        return B
+
+    def _run_steps(self, steps, B):
+        for kind, arg in steps:
             if kind == "spconv":
                 self._run_spconv(arg)
             elif kind == "conv2d":
                 self._run_conv2d(arg, B)
             elif kind == "index_subm":
                 lv = self.levels[arg]
-                if "down" not in lv:       # level 0: table from the voxel coords; deeper levels get it from conv_outputs
-                    ops.hash_build(lv["coords"], lv["count"], lv["shape"], lv["table"])
-                ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], (3, 3, 3), lv["table"], out=lv["nbr"])
+                with _Timed(self, "rulebook"):
+                    if "down" not in lv:   # level 0: table from the voxel coords; deeper levels get it from conv_outputs
+                        ops.hash_build(lv["coords"], lv["count"], lv["shape"], lv["table"])
+                    ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], (3, 3, 3), lv["table"], out=lv["nbr"])
             elif kind == "index_down":
-                self._index_down(arg)
+                with _Timed(self, "rulebook"):
+                    self._index_down(arg)
             elif kind == "absmax":
                 if any(r["quant"] is not None and (r["quant"]["on"] or r["quant"]["calib"]) and r["x"] is arg
                        for r in self.sparse_convs):
@@ -561,10 +617,11 @@ class Engine:
             elif kind == "scatter_dense":
                 x, lvl = self.encoded
                 lv = self.levels[lvl]
-                ops.scatter_dense(x["buf"], lv["coords"], lv["count"], self.bev_shape, B, out=self.spatial[:B])
+                with _Timed(self, "scatter_dense"):
+                    ops.scatter_dense(x["buf"], lv["coords"], lv["count"], self.bev_shape, B, out=self.spatial[:B])
             elif kind == "decode_nms":
-                self._decode_nms(B)
-        return B
+                with _Timed(self, "decode_nms"):
+                    self._decode_nms(B)
 
     def _index_down(self, li):
         lv_in, lv_out = self.levels[li - 1], self.levels[li]
