@@ -285,7 +285,7 @@ class Engine:
                 if is_q:
                     cpad = (cout + 3) // 4 * 4
                     if cpad != cout:    # pad the output channels to the 16-byte store granularity
-                        wk = torch.cat([wk, torch.zeros((cpad - cout, wk.shape[1]))], 0)
+                        wk = torch.cat([wk, torch.zeros((cpad - cout, wk.shape[1]), device=wk.device)], 0)
                         g.Cout = cpad
                     rec["kind"] = "i8"
                     rec["weight"] = wk.contiguous().to(dev)

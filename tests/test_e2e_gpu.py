@@ -95,7 +95,7 @@ def test_centerpoint_int8_vs_oracle(dev, recipe):
         _, idx, shape = trace["levels"][name]
         m, co, order = _sorted_level(eng, li, shape)
         assert m == len(idx)
-        np.testing.assert_array_equal(co[order], idx)
+        np.testing.assert_array_equal(co[order], idx[np.argsort(OS._key(idx, shape))])
     # first stage
     x1, idx1, shape1 = trace["levels"]["x_conv1"]
     m, co, order = _sorted_level(eng, 0, shape1)

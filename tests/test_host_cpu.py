@@ -1,0 +1,202 @@
+"""CPU: host-side contract of the drop-in boundary — C-ABI symbols, config loading, checkpoint keys and layout adaptor,
+quantization surgery (which module becomes what), loud failure without a GPU."""
+import ctypes
+import logging
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from amdq3d import lib
+    hdr = open(os.path.join(ROOT, "include", "aq3d.h")).read()
+    declared = set(re.findall(r"\b(aq3d_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(lib.SIGNATURES), declared ^ set(lib.SIGNATURES)
+    L = lib.load()                                      # raises if the .so or any symbol is missing
+    assert L.aq3d_abi_version() == lib.ABI_VERSION
+    assert L.aq3d_last_error_string() is not None
+    # struct layouts the binding relies on
+    assert ctypes.sizeof(lib.VoxelCfg) == 3 * 4 + 3 * 4 + 3 * 4 + 5 * 4
+    assert ctypes.sizeof(lib.Conv2dGeom) == 14 * 4
+    # host-only size queries work without a GPU
+    assert L.aq3d_voxelize_workspace_bytes(150000) > 150000 * 16
+    assert L.aq3d_sq_param_bytes(256, 128, 3) >= 256 * 9 * 128
+    assert L.aq3d_nms_workspace_bytes(500) >= 500 * 8 * 8
+
+
+def test_argument_validation_returns_codes_not_exit():
+    """Unlike the reference's CHECK_* macros (iou3d_nms.cpp:14-26) bad arguments come back as status + message."""
+    from amdq3d import lib
+    L = lib.load()
+    rc = L.aq3d_spconv(None, 0, None, None, 0, None, None, None, None, None, None, None, 0, 0, 0, 0, 0, None, None, None)
+    assert rc == -1 and b"null" in L.aq3d_last_error_string()
+    with pytest.raises(lib.Aq3dError):
+        lib.check(rc, "aq3d_spconv")
+    g = lib.Conv2dGeom()
+    rc = L.aq3d_conv2d_i8(None, None, ctypes.byref(g), None, None, None, None, None)
+    assert rc < 0
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from amdq3d import lib
+    with pytest.raises(lib.Aq3dError):
+        lib.load(str(tmp_path / "nope.so"))
+
+
+def test_config_loader_base_include_and_overrides():
+    from amdq3d.config import AttrDict, cfg_from_list, cfg_from_yaml_file
+    cfg = cfg_from_yaml_file("cfgs/waymo_models/centerpoint.yaml", AttrDict())
+    assert cfg.DATA_CONFIG.POINT_CLOUD_RANGE == [-75.2, -75.2, -2, 75.2, 75.2, 4]          # from _BASE_CONFIG_
+    assert cfg.MODEL.DENSE_HEAD.POST_PROCESSING.NMS_CONFIG.NMS_POST_MAXSIZE == 500
+    assert cfg.MODEL.BACKBONE_3D.get("USE_BIAS", None) is None
+    cfg_from_list(["MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH", "0.3"], cfg)
+    assert cfg.MODEL.DENSE_HEAD.POST_PROCESSING.SCORE_THRESH == 0.3
+    nus = cfg_from_yaml_file("cfgs/nuscenes_models/cbgs_voxel0075_res3d_centerpoint.yaml", AttrDict())
+    assert nus.DATA_CONFIG.POINT_CLOUD_RANGE == [-54.0, -54.0, -5.0, 54.0, 54.0, 3.0]      # model yaml overrides the base
+    assert nus.DATA_CONFIG.MAX_SWEEPS == 10 and len(nus.MODEL.DENSE_HEAD.CLASS_NAMES_EACH_HEAD) == 6
+
+
+def _model(kind="waymo"):
+    from amdq3d.config import AttrDict, cfg_from_yaml_file
+    from amdq3d.datasets import SyntheticDataset
+    from amdq3d.detector import build_network
+    path = {"waymo": "cfgs/waymo_models/centerpoint.yaml", "nuscenes": "cfgs/nuscenes_models/cbgs_voxel0075_res3d_centerpoint.yaml"}[kind]
+    cfg = cfg_from_yaml_file(path, AttrDict())
+    ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_frames=1)
+    return cfg, ds, build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+
+
+def test_state_dict_key_and_shape_contract():
+    """the checkpoint keys / shapes of the reference's Waymo CenterPoint."""
+    cfg, ds, m = _model()
+    sd = m.state_dict()
+    exp = {
+        "global_step": (1,),
+        "backbone_3d.conv_input.0.weight": (16, 3, 3, 3, 5),
+        "backbone_3d.conv_input.1.running_var": (16,),
+        "backbone_3d.conv1.0.conv1.weight": (16, 3, 3, 3, 16), "backbone_3d.conv1.1.conv2.bias": (16,),
+        "backbone_3d.conv1.0.bn2.num_batches_tracked": (),
+        "backbone_3d.conv2.0.0.weight": (32, 3, 3, 3, 16), "backbone_3d.conv2.0.1.weight": (32,),
+        "backbone_3d.conv3.2.conv2.weight": (64, 3, 3, 3, 64), "backbone_3d.conv4.0.0.weight": (128, 3, 3, 3, 64),
+        "backbone_3d.conv_out.0.weight": (128, 3, 1, 1, 128),
+        "backbone_2d.blocks.0.1.weight": (128, 256, 3, 3), "backbone_2d.blocks.0.16.weight": (128, 128, 3, 3),
+        "backbone_2d.blocks.0.17.running_mean": (128,), "backbone_2d.blocks.1.1.weight": (256, 128, 3, 3),
+        "backbone_2d.blocks.1.16.weight": (256, 256, 3, 3), "backbone_2d.deblocks.0.0.weight": (128, 256, 1, 1),
+        "backbone_2d.deblocks.1.0.weight": (256, 256, 2, 2), "backbone_2d.deblocks.1.1.bias": (256,),
+        "dense_head.shared_conv.0.weight": (64, 512, 3, 3), "dense_head.shared_conv.0.bias": (64,),
+        "dense_head.heads_list.0.center.0.0.weight": (64, 64, 3, 3), "dense_head.heads_list.0.center.1.weight": (2, 64, 3, 3),
+        "dense_head.heads_list.0.center_z.1.bias": (1,), "dense_head.heads_list.0.dim.1.weight": (3, 64, 3, 3),
+        "dense_head.heads_list.0.rot.1.weight": (2, 64, 3, 3), "dense_head.heads_list.0.hm.1.weight": (3, 64, 3, 3),
+        "dense_head.heads_list.0.hm.0.1.running_var": (64,),
+    }
+    for k, shp in exp.items():
+        assert k in sd, k
+        assert tuple(sd[k].shape) == shp, (k, tuple(sd[k].shape))
+    assert not any(".bias" in k and k.startswith("backbone_3d.conv2.0.0") for k in sd)      # post_act_block convs: bias=False
+    assert "backbone_3d.conv_input.0.bias" not in sd and "backbone_2d.blocks.0.1.bias" not in sd
+    assert float(m.dense_head.heads_list[0].hm[1].bias[0]) == pytest.approx(-2.19)
+    assert sum(p.numel() for p in m.parameters()) == pytest.approx(7.76e6, rel=0.01)
+    assert m.backbone_3d.sparse_shape == [41, 1504, 1504]
+    assert m.class_names == ["Vehicle", "Pedestrian", "Cyclist"] and m.num_class == 3 and len(m.module_list) == 5
+    _, _, mn = _model("nuscenes")
+    assert "dense_head.heads_list.5.vel.1.weight" in mn.state_dict()
+    assert tuple(mn.state_dict()["backbone_3d.conv_input.0.weight"].shape) == (16, 3, 3, 3, 5)
+
+
+def test_load_params_from_file_and_spconv1_layout_adaptor(tmp_path):
+    from amdq3d.synthetic import init_synthetic_weights, save_checkpoint
+    cfg, ds, src = _model()
+    init_synthetic_weights(src, 11)
+    log = logging.getLogger("t")
+    with pytest.raises(FileNotFoundError):
+        src.load_params_from_file(str(tmp_path / "missing.pth"), log)
+    p = str(tmp_path / "ck.pth")
+    save_checkpoint(src, p)
+    _, _, dst = _model()
+    dst.load_params_from_file(p, log, to_cpu=True)
+    for k, v in src.state_dict().items():
+        assert torch.equal(v, dst.state_dict()[k]), k
+    # spconv-1.x checkpoint: sparse conv weights stored (k1, k2, k3, c_in, c_out)
+    st = {k: v.clone() for k, v in src.state_dict().items()}
+    from amdq3d.modules import find_all_spconv_keys
+    keys = find_all_spconv_keys(src)
+    assert "backbone_3d.conv_input.0.weight" in keys and "backbone_3d.conv4.2.conv2.weight" in keys and len(keys) == 21
+    for k in keys:
+        st[k] = st[k].permute(1, 2, 3, 4, 0).contiguous()
+    st["unknown.extra"] = torch.zeros(3)
+    torch.save({"model_state": st, "version": "x"}, p)
+    _, _, dst2 = _model()
+    dst2.load_params_from_file(p, log, to_cpu=True)
+    for k, v in src.state_dict().items():
+        assert torch.equal(v, dst2.state_dict()[k]), k
+
+
+def test_quant_surgery_follows_the_reference_exclusion_lists():
+    from amdq3d import quant as Q
+    from amdq3d.modules import SparseConvolution
+    cfg, ds, m = _model("nuscenes")
+    e0 = Q.surgery_epoch()
+    Q.quant(m, 8, 8, sq=True, alpha=0.5, static=False)
+    assert Q.surgery_epoch() > e0
+    mods = dict(m.named_modules())
+    assert isinstance(mods["backbone_3d.conv_input.0"], SparseConvolution)                   # backbone_no_list
+    q3d = [n for n, x in mods.items() if isinstance(x, Q.QConvNd)]
+    assert len(q3d) == 20 and all(mods[n].cw and mods[n].act_quant.axis == 1 and mods[n].w_quant.axis == 0 for n in q3d)
+    sq = sorted(n for n, x in mods.items() if isinstance(x, Q.SQConv2d))
+    assert len([n for n in sq if n.startswith("backbone_2d.blocks")]) == 12
+    assert "dense_head.shared_conv.0" in sq
+    for h in range(6):
+        for br in ("center", "center_z", "dim", "rot", "vel"):
+            assert "dense_head.heads_list.%d.%s.0.0" % (h, br) in sq
+            assert type(mods["dense_head.heads_list.%d.%s.1" % (h, br)]) is nn.Conv2d       # no_list
+        assert type(mods["dense_head.heads_list.%d.hm.0.0" % h]) is nn.Conv2d and type(mods["dense_head.heads_list.%d.hm.1" % h]) is nn.Conv2d
+    assert len(sq) == 12 + 1 + 6 * 5
+    assert all(isinstance(mods["backbone_2d.deblocks.%d.0" % i], nn.ConvTranspose2d) for i in range(2))   # never quantized
+    assert mods[sq[0]].scaling_factor == 0.5 and mods[sq[0]]._input_quantizer.axis is None
+    # parameters are shared, not copied
+    assert mods["dense_head.shared_conv.0"].weight is m.dense_head.shared_conv[0].weight
+    # sq=False recipe: every conv, per-tensor activations
+    _, _, m2 = _model()
+    Q.quant(m2, 8, 8, sq=False, alpha=0.5, static=False)
+    mods2 = dict(m2.named_modules())
+    assert isinstance(mods2["backbone_3d.conv_input.0"], Q.QConvNd) and not mods2["backbone_3d.conv_input.0"].cw
+    assert sum(isinstance(x, Q.QConvNd) for x in mods2.values()) == 21
+    assert sum(isinstance(x, Q.QuantConv2d) for x in mods2.values()) == 12 + 1 + 5 * 2
+    # calibration switches address quantizers by name suffix like quant/quantize.py:177-194
+    names = [n for n, _ in m2.named_modules() if n.endswith("_quantizer") or n.endswith("_quant")]
+    assert len(names) == 2 * 21 + 2 * 23
+
+
+def test_forward_needs_gpu_and_containers_have_no_torch_path():
+    cfg, ds, m = _model()
+    m.eval()
+    batch = ds.collate_batch([{"points": np.zeros((10, 5), np.float32), "frame_id": "x"}])
+    assert batch["points"].shape == (10, 6) and batch["batch_size"] == 1
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            m(batch)
+    with pytest.raises(RuntimeError):
+        m.backbone_3d(None)
+    with pytest.raises(RuntimeError):
+        m.dense_head(None)
+    m.train()
+    with pytest.raises(NotImplementedError):
+        m(batch)
+
+
+def test_synthetic_frame_contract():
+    cfg, ds, m = _model()
+    d = ds[0]
+    pts = d["points"]
+    assert pts.shape == (150000, 5) and pts.dtype == np.float32
+    from oracle import voxel as OV
+    f, c, n = OV.voxelize_mean(pts, ds.point_cloud_range, ds.voxel_size, 5, 150000)
+    assert len(c) == 30000 and n.max() <= 5 and n.sum() == 150000
+    d2 = ds[0]
+    assert np.array_equal(d2["points"], pts)                                              # seeded → reproducible
