@@ -16,6 +16,7 @@
 //   A and B operands of four steps with ONE ds_read_b128 each (the k order inside an MFMA is free as long as
 //   A and B agree).  Offsets for which no row of the tile has a neighbour are skipped (wave-uniform).
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -244,6 +245,11 @@ static int spconv_launch_modes(const SpconvArgs &a, int act_mode, int w_mode, hi
     return AQ3D_OK;
 }
 
+int aq3d_spconv_i8_dispatch(const int8_t *feats_in, const float *act_dequant, const int8_t *weight, const float *w_dequant,
+                            const float *bias, const float *post_scale, const float *post_shift, const float *residual,
+                            const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
+                            float *feats_out, float *absmax_out, hipStream_t stream);
+
 extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
                            int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
                            const float *post_shift, const float *residual, const int32_t *nbr,
@@ -256,6 +262,15 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
     AQ3D_REQUIRE(act_mode != AQ3D_ACT_I8 || ((cin % 16) == 0 && act_dequant), "aq3d_spconv: int8 activations need cin%%16==0 and act_dequant");
     AQ3D_REQUIRE(w_mode != AQ3D_W_I8 || ((cin % 16) == 0 && w_dequant), "aq3d_spconv: int8 weights need cin%%16==0 and w_dequant");
     AQ3D_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "aq3d_spconv: post_scale/post_shift must come together");
+    if (act_mode == AQ3D_ACT_I8 && w_mode == AQ3D_W_I8) {
+        static const bool force_f32 = getenv("AQ3D_SPCONV_F32MFMA") != nullptr;   // A/B switch: exact-f32 MFMA path
+        if (!force_f32) {
+            int rc = aq3d_spconv_i8_dispatch((const int8_t *)feats_in, act_dequant, (const int8_t *)weight, w_dequant, bias,
+                                             post_scale, post_shift, residual, nbr, count_out, cap_out, cin, cout, kvol,
+                                             (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, stream);
+            if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
+        }
+    }
     SpconvArgs a;
     a.feats_in = feats_in; a.act_dequant = act_dequant; a.weight = weight; a.w_dequant = w_dequant;
     a.bias = bias; a.post_scale = post_scale; a.post_shift = post_shift; a.residual = residual;
