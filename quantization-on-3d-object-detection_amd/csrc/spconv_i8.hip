@@ -30,6 +30,28 @@ struct SpconvI8Args {
     int cap_out, kvol, relu;
 };
 
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// 4 packed int8 → 4 fp16 (exact) in 5 VALU ops: bias to unsigned, splice each byte under the fp16 exponent of 1024
+// (0x64xx = 1024 + xx), subtract 1152 = 1024 + 128 with a packed add.
+__device__ __forceinline__ void cvt4_i8_f16(int w, f16x2 &lo, f16x2 &hi) {
+    const unsigned t = (unsigned)w ^ 0x80808080u;
+    const unsigned p0 = __builtin_amdgcn_perm(t, 0x64646464u, 0x00050004u);   // bytes: t.b0, 0x64, t.b1, 0x64
+    const unsigned p1 = __builtin_amdgcn_perm(t, 0x64646464u, 0x00070006u);   // bytes: t.b2, 0x64, t.b3, 0x64
+    const f16x2 bias = {(_Float16)1152.f, (_Float16)1152.f};
+    lo = __builtin_bit_cast(f16x2, p0) - bias;
+    hi = __builtin_bit_cast(f16x2, p1) - bias;
+}
+
+__device__ __forceinline__ f16x8 cvt8_i8_f16(int w0, int w1) {
+    f16x2 a, b, c, d;
+    cvt4_i8_f16(w0, a, b);
+    cvt4_i8_f16(w1, c, d);
+    f16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1]; r[4] = c[0]; r[5] = c[1]; r[6] = d[0]; r[7] = d[1];
+    return r;
+}
+
 template <int CIN, int COUT, int WR, int WC, int G>
 __global__ __launch_bounds__(256) void spconv_i8_kernel(SpconvI8Args a) {
     constexpr int TM = 16 * WR;
@@ -37,6 +59,8 @@ __global__ __launch_bounds__(256) void spconv_i8_kernel(SpconvI8Args a) {
     constexpr int KP = ((G * CIN + 31) / 32) * 32;   // phase K, padded to the MFMA K
     constexpr int LD = KP + 8;                       // halves per LDS row (16-byte pad: conflict-free b128 reads)
     constexpr int C16 = CIN / 16;
+    constexpr int NA = (TM * G * C16 + 255) / 256;   // gather items (16 codes) per thread per phase
+    constexpr int NW = (COUT * G * C16 + 255) / 256; // weight items (16 codes) per thread per phase
     static_assert(WR * WC == 4, "4 waves");
     static_assert(CIN % 16 == 0 && COUT % (16 * WC) == 0, "channel granularity");
 
@@ -47,11 +71,13 @@ __global__ __launch_bounds__(256) void spconv_i8_kernel(SpconvI8Args a) {
     int *nbr_s = reinterpret_cast<int *>(Bs + COUT * LD);       // [TM][27]
     float *red = reinterpret_cast<float *>(nbr_s + TM * 27);    // [WR][COUT]
     float *dq_s = red + WR * COUT;                              // [CIN]
+    int *mask_s = reinterpret_cast<int *>(dq_s + CIN);          // [0]: phases with work; [1+wr]: per 16-row block
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave % WR, wc = wave / WR;
     const int g = lane >> 4, l15 = lane & 15;
     const int kvol = a.kvol;
+    const int nphase = (kvol + G - 1) / G;
     int n = *a.count_out;
     if (n > a.cap_out) n = a.cap_out;
     const int ntiles = (n + TM - 1) / TM;
@@ -64,6 +90,7 @@ __global__ __launch_bounds__(256) void spconv_i8_kernel(SpconvI8Args a) {
             int r = row0 + t / kvol;
             nbr_s[t] = (r < n) ? a.nbr[(size_t)row0 * kvol + t] : -1;
         }
+        if (tid < 1 + WR) mask_s[tid] = 0;
         f32x4 acc_hi[NT], acc_lo[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
@@ -71,109 +98,100 @@ __global__ __launch_bounds__(256) void spconv_i8_kernel(SpconvI8Args a) {
             acc_lo[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
-
-        for (int k0 = 0; k0 < kvol; k0 += G) {
-            const int gn = min(G, kvol - k0);
-            // which 16-row blocks have a neighbour in this phase? (bit per row block)
-            int has = 0;
-            if (tid < TM) {
-                bool any = false;
-                for (int j = 0; j < gn; ++j) any |= nbr_s[tid * kvol + k0 + j] >= 0;
-                has = any ? (1 << (tid >> 4)) : 0;
+        // phase masks: bit p set iff some row (of the tile / of a 16-row block) has a neighbour among phase p's offsets
+        if (tid < TM) {
+            int bits = 0;
+            for (int k = 0; k < kvol; ++k)
+                if (nbr_s[tid * kvol + k] >= 0) bits |= 1 << (k / G);
+            if (bits) {
+                atomicOr(&mask_s[0], bits);
+                atomicOr(&mask_s[1 + (tid >> 4)], bits);
             }
-            // block-wide OR of the per-row-block bits (also the barrier that fences the previous phase's LDS reads)
-            int has_any = __syncthreads_or(has);
-            if (!has_any) continue;
-            // per-wave: does MY row block have work? recompute from LDS (cheap, 16 rows x gn)
-            bool mine = false;
-            {
-                bool any = false;
-                if (lane < 16)
-                    for (int j = 0; j < gn; ++j) any |= nbr_s[(wr * 16 + lane) * kvol + k0 + j] >= 0;
-                mine = __ballot(any) != 0ull;
-            }
+        }
+        __syncthreads();
+        const int live = mask_s[0];
+        const int mine = mask_s[1 + wr];
 
-            // ---- gather: TM rows x gn offsets x C16 chunks of 16 codes
-            for (int t = tid; t < TM * G * C16; t += 256) {
-                const int c16 = t % C16;
-                const int j = (t / C16) % G;
-                const int r = t / (C16 * G);
-                _Float16 *dh = Ahi + r * LD + j * CIN + c16 * 16;
-                _Float16 *dl = Alo + r * LD + j * CIN + c16 * 16;
-                const int src = (j < gn) ? nbr_s[r * kvol + k0 + j] : -1;
-                f16x8 h0, h1, l0, l1;
-                if (src >= 0) {
-                    const int4 q = *reinterpret_cast<const int4 *>(a.feats_in + (size_t)src * CIN + c16 * 16);
-                    const int w[4] = {q.x, q.y, q.z, q.w};
-                    float v[16];
+        int4 aq[NA], wq[NW];
+        auto prefetch = [&](int p) {
+            const int k0 = p * G, gn = min(G, kvol - k0);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        v[u * 4 + 0] = (float)(int8_t)(w[u] & 0xff);
-                        v[u * 4 + 1] = (float)(int8_t)((w[u] >> 8) & 0xff);
-                        v[u * 4 + 2] = (float)(int8_t)((w[u] >> 16) & 0xff);
-                        v[u * 4 + 3] = (float)(int8_t)((w[u] >> 24) & 0xff);
-                    }
+            for (int i = 0; i < NA; ++i) {
+                const int t = tid + 256 * i;
+                int4 v = make_int4(0, 0, 0, 0);
+                if (t < TM * G * C16) {
+                    const int c16 = t % C16, j = (t / C16) % G, r = t / (C16 * G);
+                    const int src = (j < gn) ? nbr_s[r * kvol + k0 + j] : -1;
+                    if (src >= 0) v = *reinterpret_cast<const int4 *>(a.feats_in + (size_t)src * CIN + c16 * 16);
+                }
+                aq[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const int t = tid + 256 * i;
+                int4 v = make_int4(0, 0, 0, 0);
+                if (t < COUT * G * C16) {
+                    const int c16 = t % C16, j = (t / C16) % G, o = t / (C16 * G);
+                    if (j < gn) v = *reinterpret_cast<const int4 *>(a.weight + ((size_t)(k0 + j) * COUT + o) * CIN + c16 * 16);
+                }
+                wq[i] = v;
+            }
+        };
+        auto store = [&]() {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int t = tid + 256 * i;
+                if (t < TM * G * C16) {
+                    const int c16 = t % C16, j = (t / C16) % G, r = t / (C16 * G);
+                    const int w[4] = {aq[i].x, aq[i].y, aq[i].z, aq[i].w};
+                    f16x8 h0, h1, l0, l1;
 #pragma unroll
                     for (int u = 0; u < 16; ++u) {
-                        const float x = __fmul_rn(v[u], dq_s[c16 * 16 + u]);
+                        const float q = (float)(int8_t)((w[u >> 2] >> (8 * (u & 3))) & 0xff);
+                        const float x = __fmul_rn(q, dq_s[c16 * 16 + u]);       // the reference's fake-quantised value
                         const _Float16 h = (_Float16)x;
                         const _Float16 l = (_Float16)__fmul_rn(__fsub_rn(x, (float)h), 2048.f);
                         if (u < 8) { h0[u] = h; l0[u] = l; } else { h1[u - 8] = h; l1[u - 8] = l; }
                     }
-                } else {
+                    _Float16 *dh = Ahi + r * LD + j * CIN + c16 * 16;
+                    _Float16 *dl = Alo + r * LD + j * CIN + c16 * 16;
+                    *reinterpret_cast<f16x8 *>(dh) = h0;
+                    *reinterpret_cast<f16x8 *>(dh + 8) = h1;
+                    *reinterpret_cast<f16x8 *>(dl) = l0;
+                    *reinterpret_cast<f16x8 *>(dl + 8) = l1;
+                }
+            }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { h0[u] = h1[u] = l0[u] = l1[u] = (_Float16)0.f; }
-                }
-                *reinterpret_cast<f16x8 *>(dh) = h0;
-                *reinterpret_cast<f16x8 *>(dh + 8) = h1;
-                *reinterpret_cast<f16x8 *>(dl) = l0;
-                *reinterpret_cast<f16x8 *>(dl + 8) = l1;
-            }
-            // zero the K padding (G*CIN not a multiple of 32)
-            if constexpr (KP > G * CIN) {
-                for (int t = tid; t < TM * (KP - G * CIN); t += 256) {
-                    const int r = t / (KP - G * CIN), c = G * CIN + t % (KP - G * CIN);
-                    Ahi[r * LD + c] = (_Float16)0.f;
-                    Alo[r * LD + c] = (_Float16)0.f;
+            for (int i = 0; i < NW; ++i) {
+                const int t = tid + 256 * i;
+                if (t < COUT * G * C16) {
+                    const int c16 = t % C16, j = (t / C16) % G, o = t / (C16 * G);
+                    _Float16 *dst = Bs + o * LD + j * CIN + c16 * 16;
+                    *reinterpret_cast<f16x8 *>(dst) = cvt8_i8_f16(wq[i].x, wq[i].y);
+                    *reinterpret_cast<f16x8 *>(dst + 8) = cvt8_i8_f16(wq[i].z, wq[i].w);
                 }
             }
-            // ---- weights: COUT x gn x C16 chunks, int8 → fp16 (exact)
-            for (int t = tid; t < COUT * G * C16; t += 256) {
-                const int c16 = t % C16;
-                const int j = (t / C16) % G;
-                const int o = t / (C16 * G);
-                _Float16 *dst = Bs + o * LD + j * CIN + c16 * 16;
-                f16x8 b0, b1;
-                if (j < gn) {
-                    const int4 q = *reinterpret_cast<const int4 *>(a.weight + ((size_t)(k0 + j) * COUT + o) * CIN + c16 * 16);
-                    const int w[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        b0[u * 4 + 0] = (_Float16)(float)(int8_t)(w[u] & 0xff);
-                        b0[u * 4 + 1] = (_Float16)(float)(int8_t)((w[u] >> 8) & 0xff);
-                        b0[u * 4 + 2] = (_Float16)(float)(int8_t)((w[u] >> 16) & 0xff);
-                        b0[u * 4 + 3] = (_Float16)(float)(int8_t)((w[u] >> 24) & 0xff);
-                        b1[u * 4 + 0] = (_Float16)(float)(int8_t)(w[u + 2] & 0xff);
-                        b1[u * 4 + 1] = (_Float16)(float)(int8_t)((w[u + 2] >> 8) & 0xff);
-                        b1[u * 4 + 2] = (_Float16)(float)(int8_t)((w[u + 2] >> 16) & 0xff);
-                        b1[u * 4 + 3] = (_Float16)(float)(int8_t)((w[u + 2] >> 24) & 0xff);
-                    }
-                } else {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) { b0[u] = b1[u] = (_Float16)0.f; }
-                }
-                *reinterpret_cast<f16x8 *>(dst) = b0;
-                *reinterpret_cast<f16x8 *>(dst + 8) = b1;
+        };
+        // the K padding columns (G*CIN not a multiple of 32) are written once per tile: zeros
+        if constexpr (KP > G * CIN) {
+            constexpr int PADC = KP - G * CIN;
+            for (int t = tid; t < (2 * TM + COUT) * PADC; t += 256) {
+                const int r = t / PADC, c = G * CIN + t % PADC;
+                Ahi[r * LD + c] = (_Float16)0.f;     // Ahi, Alo and Bs are contiguous with the same row pitch
             }
-            if constexpr (KP > G * CIN) {
-                for (int t = tid; t < COUT * (KP - G * CIN); t += 256) {
-                    const int o = t / (KP - G * CIN), c = G * CIN + t % (KP - G * CIN);
-                    Bs[o * LD + c] = (_Float16)0.f;
-                }
-            }
-            __syncthreads();
+        }
 
-            if (mine) {
+        int p = live ? (__ffs(live) - 1) : nphase;
+        if (p < nphase) prefetch(p);
+        while (p < nphase) {
+            __syncthreads();            // every wave is done reading the previous phase's tiles
+            store();
+            __syncthreads();
+            const int rest = live & ~((2 << p) - 1);
+            const int pn = rest ? (__ffs(rest) - 1) : nphase;
+            if (pn < nphase) prefetch(pn);  // global loads fly under the MFMAs below
+            if ((mine >> p) & 1) {
+                const int gn = min(G, kvol - p * G);
                 const _Float16 *ah = Ahi + (wr * 16 + l15) * LD + 8 * g;
                 const _Float16 *al = Alo + (wr * 16 + l15) * LD + 8 * g;
                 const _Float16 *bb = Bs + ((wc * NT) * 16 + l15) * LD + 8 * g;
@@ -190,6 +208,7 @@ __global__ __launch_bounds__(256) void spconv_i8_kernel(SpconvI8Args a) {
                     }
                 }
             }
+            p = pn;
         }
 
         // ---- epilogue (D layout: col = lane&15 → out channel, row = 4g + reg → tile row)
@@ -240,7 +259,7 @@ template <int CIN, int COUT, int WR, int WC, int G>
 static int launch_i8(const SpconvI8Args &a, hipStream_t stream) {
     constexpr int TM = 16 * WR;
     constexpr int KP = ((G * CIN + 31) / 32) * 32;
-    constexpr size_t lds = (size_t)(2 * TM + COUT) * (KP + 8) * 2 + (size_t)TM * 27 * 4 + (size_t)WR * COUT * 4 + CIN * 4;
+    constexpr size_t lds = (size_t)(2 * TM + COUT) * (KP + 8) * 2 + (size_t)TM * 27 * 4 + (size_t)WR * COUT * 4 + CIN * 4 + 32;
     const int tiles = aq3d_div_up(a.cap_out, TM);
     const int grid = tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096;
     auto kern = spconv_i8_kernel<CIN, COUT, WR, WC, G>;
