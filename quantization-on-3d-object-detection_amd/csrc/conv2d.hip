@@ -15,6 +15,7 @@
 // Workgroup = 256 threads = 2x2 waves; wave tile = (TI*16) channels x (TJ*16) pixels.
 #include "common.h"
 #include "sq_layout.h"
+#include <stdlib.h>
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -360,15 +361,25 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
     a.scal = (const float *)(base + l.scal);
     a.w = base + l.wq;
     const int L = g->Ho * g->Wo;
+    // pixel-tile width: enough workgroups for >= 2 per CU (the K loop is a latency chain, it needs co-resident partners)
+    static const int force_bn = getenv("AQ3D_I8_BN") ? atoi(getenv("AQ3D_I8_BN")) : 0;
+    const int ocb = g->Cout >= 128 ? aq3d_div_up(g->Cout, 128) : aq3d_div_up(g->Cout, 64);
+    int bn = 128;
+    if (aq3d_div_up(L, 128) * ocb < 512) bn = 64;
+    if (aq3d_div_up(L, 64) * ocb < 512) bn = 32;
+    if (force_bn) bn = force_bn;
+#define AQ3D_I8_LAUNCH(TI_, TJ_) \
+    hipLaunchKernelGGL((conv2d_i8_kernel<TI_, TJ_>), dim3(aq3d_div_up(L, 32 * TJ_), ocb), dim3(256), 0, stream, a)
     if (g->Cout >= 128) {
-        if (L >= 128 * 200) {
-            hipLaunchKernelGGL((conv2d_i8_kernel<4, 4>), dim3(aq3d_div_up(L, 128), aq3d_div_up(g->Cout, 128)), dim3(256), 0, stream, a);
-        } else {
-            hipLaunchKernelGGL((conv2d_i8_kernel<4, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(g->Cout, 128)), dim3(256), 0, stream, a);
-        }
+        if (bn == 128) AQ3D_I8_LAUNCH(4, 4);
+        else if (bn == 64) AQ3D_I8_LAUNCH(4, 2);
+        else AQ3D_I8_LAUNCH(4, 1);
     } else {
-        hipLaunchKernelGGL((conv2d_i8_kernel<2, 4>), dim3(aq3d_div_up(L, 128), aq3d_div_up(g->Cout, 64)), dim3(256), 0, stream, a);
+        if (bn == 128) AQ3D_I8_LAUNCH(2, 4);
+        else if (bn == 64) AQ3D_I8_LAUNCH(2, 2);
+        else AQ3D_I8_LAUNCH(2, 1);
     }
+#undef AQ3D_I8_LAUNCH
     AQ3D_CHECK_LAUNCH("aq3d_conv2d_i8");
     return AQ3D_OK;
 }

@@ -62,16 +62,22 @@ __device__ __forceinline__ float sigmoidf_dev(float x) { return __fdiv_rn(1.0f, 
 // grid = num_classes, block = 1024. Writes K composite keys (score bits << 32 | ~index) per class, sorted descending;
 // slots beyond the number of pixels hold 0.
 __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__restrict__ hm, int hm_ld, int L, int K,
-                                                              int Kpad, u64 *__restrict__ out) {
+                                                              int Kpad, int cache_keys, u64 *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *sel = reinterpret_cast<u64 *>(smem_raw);          // [Kpad]
     int *hist = reinterpret_cast<int *>(sel + Kpad);       // [256]
     int *sh = hist + 256;                                  // [16]
+    unsigned int *keys_s = reinterpret_cast<unsigned int *>(sh + 16);   // [L] score bit patterns (when they fit in LDS)
     __shared__ unsigned int s_prefix;
     __shared__ int s_remaining, s_fill;
     const int cls = blockIdx.x;
     const float *col = hm + cls;
     const int Keff = K < L ? K : L;
+    auto key_of = [&](int i) -> unsigned int {
+        return cache_keys ? keys_s[i] : __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
+    };
+    if (cache_keys)
+        for (int i = threadIdx.x; i < L; i += blockDim.x) keys_s[i] = __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
 
     // 4-pass MSB radix select on the 32-bit score keys: find T = Keff-th largest key
     if (threadIdx.x == 0) { s_prefix = 0u; s_remaining = Keff; }
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
         const unsigned int prefix = s_prefix;
         const unsigned int pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
         for (int i = threadIdx.x; i < L; i += blockDim.x) {
-            unsigned int key = __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
+            unsigned int key = key_of(i);
             if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1);
         }
         __syncthreads();
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
     __syncthreads();
     // keys > T in any order (sorted afterwards)
     for (int i = threadIdx.x; i < L; i += blockDim.x) {
-        unsigned int key = __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
+        unsigned int key = key_of(i);
         if (key > T) {
             int pos = atomicAdd(&s_fill, 1);
             sel[pos] = ((u64)key << 32) | (u64)(0xffffffffu - (unsigned int)i);
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
     for (int base = 0; base < L && taken < need_ties; base += blockDim.x) {
         const int i = base + threadIdx.x;
         int f = 0;
-        if (i < L) f = (__float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld])) == T) ? 1 : 0;
+        if (i < L) f = (key_of(i) == T) ? 1 : 0;
         int tot;
         int pos = block_scan_excl_1024(f, sh, &tot);
         if (f && taken + pos < need_ties) sel[gt + taken + pos] = ((u64)T << 32) | (u64)(0xffffffffu - (unsigned int)i);
@@ -222,7 +228,11 @@ extern "C" int aq3d_center_decode(const float *hm, const float *center, const fl
     const int Kpad = next_pow2(K);
     u64 *cand = (u64 *)workspace;
     size_t lds1 = (size_t)Kpad * 8 + 256 * 4 + 16 * 4;
-    hipLaunchKernelGGL(topk_per_class_kernel, dim3(cfg->num_classes), dim3(1024), lds1, stream, hm, cfg->hm_ld, L, K, Kpad, cand);
+    const int cache_keys = (lds1 + (size_t)L * 4 <= 150 * 1024) ? 1 : 0;   // one workgroup may use up to 160 KiB of LDS
+    if (cache_keys) lds1 += (size_t)L * 4;
+    if (lds1 > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(topk_per_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipLaunchKernelGGL(topk_per_class_kernel, dim3(cfg->num_classes), dim3(1024), lds1, stream, hm, cfg->hm_ld, L, K, Kpad, cache_keys, cand);
     const int ncand = cfg->num_classes * K;
     const int Npad = next_pow2(ncand);
     DecodeParams q;
@@ -355,18 +365,29 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
     if (threadIdx.x == 0) mask[(size_t)row * col_blocks + cb] = word;
 }
 
-// greedy sweep by a single wave, 64 boxes per step; lane w owns removal word w (cap <= 4096 → <= 64 words)
-__global__ __launch_bounds__(64) void nms_sweep_kernel(const u64 *__restrict__ mask, const int *count, int cap, int col_blocks,
-                                                       int post_max, int *__restrict__ keep, int *__restrict__ keep_count) {
+// greedy sweep, 64 boxes per step; the bitmask is staged in LDS by the whole workgroup when it fits, then wave 0 sweeps:
+// lane w owns removal word w (cap <= 4096 → <= 64 words).
+__global__ __launch_bounds__(256) void nms_sweep_kernel(const u64 *__restrict__ mask, const int *count, int cap, int col_blocks,
+                                                       int post_max, int use_lds, int *__restrict__ keep, int *__restrict__ keep_count) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *mask_s = reinterpret_cast<u64 *>(smem_raw);
     int n = *count;
     if (n > cap) n = cap;
+    const u64 *msrc = mask;
+    if (use_lds) {
+        const int words = n * col_blocks;
+        for (int i = threadIdx.x; i < words; i += blockDim.x) mask_s[i] = mask[i];
+        __syncthreads();
+        msrc = mask_s;
+    }
+    if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
     u64 remv = 0ull;
     int num = 0;
     const int nb = (n + 63) >> 6;
     for (int b = 0; b < nb; ++b) {
         const int row = b * 64 + lane;
-        const u64 diag = (row < n) ? mask[(size_t)row * col_blocks + b] : 0ull;
+        const u64 diag = (row < n) ? msrc[(size_t)row * col_blocks + b] : 0ull;
         u64 cur = __shfl(remv, b, 64);
         u64 kept = 0ull;
         const int lim = min(64, n - b * 64);
@@ -381,11 +402,11 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const u64 *__restrict__ m
         }
         num += __popcll(kept);
         if (lane > b && lane < col_blocks) {
-            u64 k2 = kept;
-            while (k2) {
-                const int t = __ffsll((long long)k2) - 1;
-                k2 &= k2 - 1ull;
-                remv |= mask[(size_t)(b * 64 + t) * col_blocks + lane];
+#pragma unroll 8
+            for (int t = 0; t < 64; ++t) {
+                const int r = b * 64 + t;
+                const u64 m = (r < n) ? msrc[(size_t)r * col_blocks + lane] : 0ull;
+                if ((kept >> t) & 1ull) remv |= m;
             }
         }
     }
@@ -410,7 +431,12 @@ extern "C" int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_
     const int col_blocks = aq3d_div_up(cap, 64);
     u64 *mask = (u64 *)workspace;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cap, col_blocks), dim3(64), 0, stream, boxes, box_ld, count, cap, thresh, col_blocks, mask);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(64), 0, stream, mask, count, cap, col_blocks, post_max, keep_out, keep_count);
+    const size_t mask_bytes = (size_t)cap * col_blocks * sizeof(u64);
+    const int use_lds = mask_bytes <= 128 * 1024;
+    if (use_lds && mask_bytes > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_bytes);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), use_lds ? mask_bytes : 0, stream, mask, count, cap, col_blocks, post_max,
+                       use_lds, keep_out, keep_count);
     AQ3D_CHECK_LAUNCH("aq3d_nms_rotated");
     return AQ3D_OK;
 }

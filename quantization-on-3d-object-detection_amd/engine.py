@@ -257,6 +257,7 @@ class Engine:
         self.spatial = torch.zeros((B, H, W, Cenc * D), dtype=f32, device=dev)
         self.steps.append(("scatter_dense", None))
         self.dense_convs = []
+        self._pieces = {}
 
         def compile_conv2d(mod, path, x, xH, xW, x_ld, pad_extra, bn, relu, out=None, out_ld=None, out_coff=0):
             """mod: nn.Conv2d | SQConv2d | QuantConv2d | nn.ConvTranspose2d. x: [B, xH, xW, x_ld] buffer."""
@@ -291,7 +292,11 @@ class Engine:
                     rec["weight"] = wk.contiguous().to(dev)
                     rec["w_colmax"] = rec["weight"].abs().max(dim=0)[0].contiguous()
                     rec["alpha"] = mod.scaling_factor
-                    rec["pieces"] = self.arena.alloc(16 * cin)
+                    pkey = (x.data_ptr(), x_ld, cin, xH, xW)      # one abs-max pass per input tensor, shared by its consumers
+                    rec["pieces_owner"] = pkey not in self._pieces
+                    if rec["pieces_owner"]:
+                        self._pieces[pkey] = self.arena.alloc(16 * cin)
+                    rec["pieces"] = self._pieces[pkey]
                     rec["params"] = torch.empty((ops.sq_param_bytes(cin, g.Cout, k),), dtype=torch.uint8, device=dev)
                     wq_, iq_ = mod._weight_quantizer, mod._input_quantizer
                     rec["w_bits"], rec["a_bits"] = wq_.num_bits, iq_.num_bits
@@ -522,9 +527,10 @@ class Engine:
         x, out = rec["x"], rec["out"]
         if rec["kind"] == "i8":
             pieces = self.arena.view(rec["pieces"], (16, g.Cin))
-            with _Timed(self, "piece_absmax"):
-                for b in range(B):
-                    ops.piece_absmax(x[b], g.H, g.W, g.Cin, g.in_ld, pieces)
+            if rec["pieces_owner"]:
+                with _Timed(self, "piece_absmax"):
+                    for b in range(B):
+                        ops.piece_absmax(x[b], g.H, g.W, g.Cin, g.in_ld, pieces)
             with _Timed(self, "sq_prep"):
                 ops.sq_prep(pieces, rec["weight"], rec["w_colmax"], g, rec["alpha"], rec["params"], rec["w_bits"],
                             rec["a_bits"], rec["static_x"], rec["static_w"])
