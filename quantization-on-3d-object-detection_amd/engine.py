@@ -172,6 +172,8 @@ class Engine:
             rec = dict(path=path, cin=cin, cout=cout, kvol=kvol, x=x, nbr=nbr, level=level_out, relu=relu,
                        residual=residual, quant=None)
             quant_on = q is not None and q.w_quant._if_quant
+            if q is not None and q.w_quant._if_calib:       # constant weights: the max calibrator sees the same amax every batch
+                q.w_quant.collect(torch.from_numpy(np.abs(np.moveaxis(w, 2, 1).reshape(cout, -1)).max(axis=1)))
             if quant_on:
                 codes, wdq, _ = quantize_weight_rows(np.moveaxis(w, 2, 1).reshape(cout, -1), q.w_bits)   # [oc, ic*k^3] view
                 codes = np.moveaxis(codes.reshape(cout, cin, kvol), 1, 2)                               # back to [cout,kvol,cin]

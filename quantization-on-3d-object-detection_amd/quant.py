@@ -229,3 +229,32 @@ def quantize_weight_rows(w2d, bits):
     div = np.where(zero, np.float32(1), scale).astype(np.float32)
     codes = np.clip(np.rint(w * mul), -qmax - 1, qmax)
     return codes, (np.float32(1.0) / div).reshape(-1).astype(np.float32), amax.reshape(-1)
+
+
+# ================================ persisted calibration state (the reference recomputes PTQ every run) ===========
+def quant_state_dict(model):
+    """{quantizer module path: calibrated amax tensor} for every calibrated TensorQuantizer."""
+    return {name: m.amax.clone() for name, m in model.named_modules() if isinstance(m, TensorQuantizer) and m.amax is not None}
+
+
+def save_quant_state(model, path):
+    torch.save({"quant_state": quant_state_dict(model), "version": 1}, path)
+
+
+def load_quant_state(model, path_or_state, strict=True):
+    """Restore calibrated amax values onto a model that went through the same surgery. Returns the loaded names."""
+    state = path_or_state
+    if not isinstance(state, dict):
+        state = torch.load(path_or_state, map_location="cpu", weights_only=False)
+    state = state.get("quant_state", state)
+    mods = {name: m for name, m in model.named_modules() if isinstance(m, TensorQuantizer)}
+    missing = [k for k in state if k not in mods]
+    if strict and missing:
+        raise KeyError("quant state has no matching quantizer for: %s" % ", ".join(missing[:5]))
+    loaded = []
+    for k, v in state.items():
+        if k in mods:
+            mods[k]._amax = v.detach().float().cpu().reshape(-1).clone()
+            loaded.append(k)
+    _touch()
+    return loaded

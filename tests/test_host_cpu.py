@@ -200,3 +200,28 @@ def test_synthetic_frame_contract():
     assert len(c) == 30000 and n.max() <= 5 and n.sum() == 150000
     d2 = ds[0]
     assert np.array_equal(d2["points"], pts)                                              # seeded → reproducible
+
+
+def test_quant_state_save_load_roundtrip(tmp_path):
+    from amdq3d import quant as Q
+    _, _, m = _model()
+    Q.quant(m, 8, 8, sq=True, alpha=0.5, static=False)
+    qs = {n: x for n, x in m.named_modules() if isinstance(x, Q.TensorQuantizer)}
+    for i, (n, q) in enumerate(sorted(qs.items())):
+        if i % 2 == 0:
+            q.collect(torch.full((4,), float(i + 1)))
+    Q.compute_amax(m)
+    st = Q.quant_state_dict(m)
+    assert len(st) == (len(qs) + 1) // 2
+    p = str(tmp_path / "q.pth")
+    Q.save_quant_state(m, p)
+    _, _, m2 = _model()
+    Q.quant(m2, 8, 8, sq=True, alpha=0.5, static=False)
+    e0 = Q.surgery_epoch()
+    loaded = Q.load_quant_state(m2, p)
+    assert sorted(loaded) == sorted(st) and Q.surgery_epoch() > e0
+    for n, v in Q.quant_state_dict(m2).items():
+        assert torch.equal(v, st[n])
+    _, _, m3 = _model()                                   # no surgery → no quantizers → strict load must complain
+    with pytest.raises(KeyError):
+        Q.load_quant_state(m3, p)
