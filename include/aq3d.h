@@ -129,18 +129,22 @@ int aq3d_absmax_cols(const float *x, const int32_t *count, int32_t cap, int32_t 
  *   codes_out  i8  [cap, C] integer codes (may be NULL; only for bits <= 8)
  *   fq_out     f32 [cap, C] fake-quantized values q/scale_c (may be NULL)
  *   dequant_out f32 [C]     1/scale_c                      (may be NULL)
+ *   split_out  f16 [cap, 2C] the fake-quantized value v = q/scale_c as an fp16 pair, row = [hi(C) | lo(C)],
+ *                           hi = fp16(v), lo = fp16((v - hi) * 2048): v = hi + lo/2048 to 22 bits (may be NULL)
  *   per_tensor != 0: one amax = max_c amax_c is used for every column (QuantDescriptor without axis). */
 int aq3d_quantize_rows(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C,
                        int32_t bits, int32_t per_tensor, int8_t *codes_out, float *fq_out,
-                       float *dequant_out, void *stream);
+                       float *dequant_out, void *split_out, void *stream);
 
 enum {
     AQ3D_ACT_F32 = 0,  /* feats_in is f32 [*, Cin] used as is                       */
-    AQ3D_ACT_I8 = 1    /* feats_in is i8 codes [*, Cin]; value = code * act_dequant[c] (scale folded into the gather) */
+    AQ3D_ACT_I8 = 1,   /* feats_in is i8 codes [*, Cin]; value = code * act_dequant[c] (scale folded into the gather) */
+    AQ3D_ACT_F16SPLIT = 2 /* feats_in is the f16 [*, 2*Cin] hi|lo pair written by aq3d_quantize_rows(split_out) */
 };
 enum {
-    AQ3D_W_F32 = 0,    /* weight is f32 [kvol, Cin, Cout]                           */
-    AQ3D_W_I8 = 1      /* weight is i8 codes [kvol, Cin, Cout]; value = code * w_dequant[cout] */
+    AQ3D_W_F32 = 0,    /* weight is f32 [kvol, Cout, Cin]                           */
+    AQ3D_W_I8 = 1,     /* weight is i8 codes [kvol, Cout, Cin]; value = code * w_dequant[cout] */
+    AQ3D_W_F16 = 2     /* weight is the same integer codes held as f16 [kvol, Cout, Cin]; value = code * w_dequant[cout] */
 };
 enum { AQ3D_FLAG_RELU = 1 };
 

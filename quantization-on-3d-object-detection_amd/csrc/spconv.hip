@@ -249,6 +249,10 @@ int aq3d_spconv_i8_dispatch(const int8_t *feats_in, const float *act_dequant, co
                             const float *bias, const float *post_scale, const float *post_shift, const float *residual,
                             const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
                             float *feats_out, float *absmax_out, hipStream_t stream);
+int aq3d_spconv_split_dispatch(const void *feats_split, const void *weight_f16, const float *w_dequant, const float *bias,
+                               const float *post_scale, const float *post_shift, const float *residual, const int *nbr,
+                               const int *count_out, int cap_out, int cin, int cout, int kvol, int relu, float *feats_out,
+                               float *absmax_out, hipStream_t stream);
 
 extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
                            int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
@@ -262,6 +266,13 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
     AQ3D_REQUIRE(act_mode != AQ3D_ACT_I8 || ((cin % 16) == 0 && act_dequant), "aq3d_spconv: int8 activations need cin%%16==0 and act_dequant");
     AQ3D_REQUIRE(w_mode != AQ3D_W_I8 || ((cin % 16) == 0 && w_dequant), "aq3d_spconv: int8 weights need cin%%16==0 and w_dequant");
     AQ3D_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "aq3d_spconv: post_scale/post_shift must come together");
+    if (act_mode == AQ3D_ACT_F16SPLIT || w_mode == AQ3D_W_F16) {
+        AQ3D_REQUIRE(act_mode == AQ3D_ACT_F16SPLIT && w_mode == AQ3D_W_F16 && w_dequant,
+                     "aq3d_spconv: f16-split activations go with f16 weight codes (+ w_dequant)");
+        return aq3d_spconv_split_dispatch(feats_in, weight, w_dequant, bias, post_scale, post_shift, residual, nbr, count_out,
+                                          cap_out, cin, cout, kvol, (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out,
+                                          stream);
+    }
     if (act_mode == AQ3D_ACT_I8 && w_mode == AQ3D_W_I8) {
         static const bool force_f32 = getenv("AQ3D_SPCONV_F32MFMA") != nullptr;   // A/B switch: exact-f32 MFMA path
         if (!force_f32) {
@@ -329,7 +340,8 @@ extern "C" int aq3d_absmax_cols(const float *x, const int32_t *count, int32_t ca
 __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restrict__ x, const float *__restrict__ amax,
                                                             const int *count, int cap, int C, float qmax,
                                                             int per_tensor, int8_t *__restrict__ codes,
-                                                            float *__restrict__ fq, float *__restrict__ dequant) {
+                                                            float *__restrict__ fq, float *__restrict__ dequant,
+                                                            _Float16 *__restrict__ split) {
     __shared__ float s_scale[256];
     __shared__ float s_div[256];
     int n = *count;
@@ -355,13 +367,20 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restr
         float q = rintf(__fmul_rn(x[t], s_scale[c]));
         q = fminf(fmaxf(q, -qmax - 1.f), qmax);
         if (codes) codes[t] = (int8_t)(int)q;
-        if (fq) fq[t] = __fdiv_rn(q, s_div[c]);
+        const float v = __fdiv_rn(q, s_div[c]);
+        if (fq) fq[t] = v;
+        if (split) {
+            const long long r = t / C;
+            const _Float16 h = (_Float16)v;
+            split[r * 2 * C + c] = h;
+            split[r * 2 * C + C + c] = (_Float16)__fmul_rn(__fsub_rn(v, (float)h), 2048.f);
+        }
     }
 }
 
 extern "C" int aq3d_quantize_rows(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C,
                                   int32_t bits, int32_t per_tensor, int8_t *codes_out, float *fq_out,
-                                  float *dequant_out, void *stream_) {
+                                  float *dequant_out, void *split_out, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AQ3D_REQUIRE(x && amax && count, "aq3d_quantize_rows: null argument");
     AQ3D_REQUIRE(C >= 1 && C <= 256, "aq3d_quantize_rows: C=%d not in 1..256", C);
@@ -369,7 +388,7 @@ extern "C" int aq3d_quantize_rows(const float *x, const float *amax, const int32
     AQ3D_REQUIRE(!(codes_out && bits > 8), "aq3d_quantize_rows: int8 codes need bits <= 8");
     const float qmax = (float)((1 << (bits - 1)) - 1);
     hipLaunchKernelGGL(quantize_rows_kernel, dim3(aq3d_grid((int64_t)cap * C, 256)), dim3(256), 0, stream, x, amax, count,
-                       cap, C, qmax, per_tensor, codes_out, fq_out, dequant_out);
+                       cap, C, qmax, per_tensor, codes_out, fq_out, dequant_out, (_Float16 *)split_out);
     AQ3D_CHECK_LAUNCH("aq3d_quantize_rows");
     return AQ3D_OK;
 }

@@ -122,6 +122,8 @@ class Engine:
         self.max_voxels = int(vcfg.MAX_NUMBER_OF_VOXELS["test"])
         cap_opt = getattr(det, "voxel_capacity", None)
         self.cap = int(cap_opt) if cap_opt else self.max_voxels * self.batch_cap
+        import os
+        self.spconv_mode = os.environ.get("AQ3D_SPCONV_MODE", "split")   # "split" (f16 hi/lo activations) | "i8" (coded gather)
         self.arena = _Arena(device)
         self.steps = []
         self.tensors = {}
@@ -178,7 +180,10 @@ class Engine:
                 codes, wdq, _ = quantize_weight_rows(np.moveaxis(w, 2, 1).reshape(cout, -1), q.w_bits)   # [oc, ic*k^3] view
                 codes = np.moveaxis(codes.reshape(cout, cin, kvol), 1, 2)                               # back to [cout,kvol,cin]
                 if q.w_bits <= 8 and cin % 16 == 0:
-                    rec["weight"] = self._dev(np.transpose(codes, (1, 0, 2)).astype(np.int8))
+                    wk = np.transpose(codes, (1, 0, 2))
+                    rec["weight_i8"] = self._dev(wk.astype(np.int8))              # canonical int8 codes [kvol, cout, cin]
+                    # staging copy of the same integers as fp16 (exact): the split-activation kernel copies it verbatim
+                    rec["weight"] = self._dev(wk.astype(np.float16)) if self.spconv_mode == "split" else rec["weight_i8"]
                     rec["w_dequant"] = self._dev(wdq)
                 else:   # fake-quantised fp32 weights through the fp32 weight path
                     wfq = (codes.astype(np.float32) * wdq[:, None, None]).astype(np.float32)
@@ -198,9 +203,11 @@ class Engine:
                 rec["quant"] = dict(bits=q.act_bits, per_tensor=not q.cw, quantizer=aq, on=aq._if_quant,
                                     calib=aq._if_calib,
                                     static_amax=None if aq.amax is None else self._dev(_np(aq.amax).reshape(-1)))
-                use_codes = q.act_bits <= 8 and cin % 16 == 0
+                use_codes = q.act_bits <= 8 and cin % 16 == 0 and rec["w_dequant"] is not None
                 rec["quant"]["use_codes"] = use_codes
-                rec["codes"] = torch.zeros((cap, cin), dtype=torch.int8, device=dev) if use_codes else None
+                split = use_codes and self.spconv_mode == "split"
+                rec["split"] = torch.zeros((cap, 2 * cin), dtype=torch.float16, device=dev) if split else None
+                rec["codes"] = torch.zeros((cap, cin), dtype=torch.int8, device=dev) if use_codes and not split else None
                 rec["fq"] = None if use_codes else torch.zeros((cap, cin), dtype=f32, device=dev)
                 rec["dq"] = torch.zeros((cin,), dtype=f32, device=dev)
             out = tensor(level_out, cout, path)
@@ -512,8 +519,10 @@ class Engine:
             with _Timed(self, "quantize_rows"):
                 ops.check(L.aq3d_quantize_rows(ops._p(x["buf"]), ops._p(amax), ops._p(in_count), self.cap, x["C"], q["bits"],
                                                int(q["per_tensor"]), ops._p(rec["codes"]), ops._p(rec["fq"]), ops._p(rec["dq"]),
-                                               ops._stream()), "aq3d_quantize_rows")
-            if q["use_codes"]:
+                                               ops._p(rec["split"]), ops._stream()), "aq3d_quantize_rows")
+            if rec["split"] is not None:
+                feats = rec["split"]
+            elif q["use_codes"]:
                 feats, act_dq = rec["codes"], rec["dq"]
             else:
                 feats = rec["fq"]
