@@ -202,11 +202,12 @@ size_t aq3d_sq_param_bytes(int32_t Cin, int32_t Cout, int32_t ksize);
  *   w_colmax   f32 [K]         max over Cout of |weight| per column (constant, computed once)
  *   alpha      SmoothQuant migration strength (scaling_factor); alpha < 0 disables smoothing (s = 1)
  *   static_amax_x > 0 / static_amax_w != NULL: calibrated amax values instead of dynamic ones
- *   params     device block of aq3d_sq_param_bytes(): s[K], 1/s[K], wq i8 [Cout,K], out_mul[Cout], sx
+ *   amax_x_acc f32 [1] accumulator for the dynamic per-tensor activation amax; the caller zeroes it once per frame
+ *   params     device block of aq3d_sq_param_bytes(): s[K], 1/s[K], out_mul[Cout], amax_w[Cout], scalars, wq i8 [Cout,K]
  */
 int aq3d_sq_prep(const float *pieces, const float *weight, const float *w_colmax,
                  const aq3d_conv2d_geom *g, float alpha, int32_t w_bits, int32_t a_bits,
-                 float static_amax_x, const float *static_amax_w, void *params, void *stream);
+                 float static_amax_x, const float *static_amax_w, float *amax_x_acc, void *params, void *stream);
 
 /* y = epilogue( int32 GEMM of quantised im2col(x) with quantised weights ) — SQConv2d.forward.
  *   epilogue: v = acc * out_mul[o] + bias[o]; y = v * post_scale[o] + post_shift[o]; relu. */

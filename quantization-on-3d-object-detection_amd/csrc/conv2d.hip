@@ -40,13 +40,24 @@ __device__ __forceinline__ float div_by_scale(float x, float s, float r) {
     return __fmaf_rn(e, r, q0);
 }
 
-__device__ __forceinline__ int quant_pack4(f32x4 v, f32x4 s, f32x4 r, float sx) {
-    float a = fminf(fmaxf(__fmul_rn(div_by_scale(v.x, s.x, r.x), sx), -128.f), 127.f);
-    float b = fminf(fmaxf(__fmul_rn(div_by_scale(v.y, s.y, r.y), sx), -128.f), 127.f);
-    float c = fminf(fmaxf(__fmul_rn(div_by_scale(v.z, s.z, r.z), sx), -128.f), 127.f);
-    float d = fminf(fmaxf(__fmul_rn(div_by_scale(v.w, s.w, r.w), sx), -128.f), 127.f);
-    int qa = __float2int_rn(a), qb = __float2int_rn(b), qc = __float2int_rn(c), qd = __float2int_rn(d);
-    return (qa & 0xff) | ((qb & 0xff) << 8) | ((qc & 0xff) << 16) | (qd << 24);
+// Quantise 4 activations to int8 codes and pack them into one dword.
+//   t = x / s (exact), u = t * sxv, code = rint(u) — rint through the 1.5*2^23 magic add (RNE by the adder, exact for
+//   |u| < 2^22): the low byte of the sum's bit pattern is the two's-complement code. sxv is the activation scale, or 0 for
+//   a pixel that falls into the zero padding (then every code is 0 whatever was loaded).
+__device__ __forceinline__ int quant_pack4(f32x4 v, f32x4 s, f32x4 r, float sxv) {
+    float u0 = __fmul_rn(div_by_scale(v.x, s.x, r.x), sxv);
+    float u1 = __fmul_rn(div_by_scale(v.y, s.y, r.y), sxv);
+    float u2 = __fmul_rn(div_by_scale(v.z, s.z, r.z), sxv);
+    float u3 = __fmul_rn(div_by_scale(v.w, s.w, r.w), sxv);
+    // clamp (one v_med3 each): only a calibrated (static) amax can actually be exceeded
+    u0 = __builtin_amdgcn_fmed3f(u0, -128.f, 127.f); u1 = __builtin_amdgcn_fmed3f(u1, -128.f, 127.f);
+    u2 = __builtin_amdgcn_fmed3f(u2, -128.f, 127.f); u3 = __builtin_amdgcn_fmed3f(u3, -128.f, 127.f);
+    const float magic = 12582912.0f;
+    const unsigned b0 = __float_as_uint(__fadd_rn(u0, magic)), b1 = __float_as_uint(__fadd_rn(u1, magic));
+    const unsigned b2 = __float_as_uint(__fadd_rn(u2, magic)), b3 = __float_as_uint(__fadd_rn(u3, magic));
+    const unsigned lo = __builtin_amdgcn_perm(b1, b0, 0x0c0c0400u);   // bytes: b0.0, b1.0, 0, 0
+    const unsigned hi = __builtin_amdgcn_perm(b3, b2, 0x04000c0cu);   // bytes: 0, 0, b2.0, b3.0
+    return (int)(lo | hi);
 }
 
 // ------------------------------------------------------------------ int8 SmoothQuant conv
@@ -73,55 +84,58 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvArgs a) {
     const int nk = a.ks * a.ks * cchunks;
     const float sx = a.scal[0];
 
-    // staging roles
+    // staging roles: thread = (channel quad cq, pixel group pg); per pixel the element offset of tap (0,0) and a 9-bit
+    // mask of the taps that fall inside the image are computed ONCE; a K step only adds a wave-uniform tap offset.
     const int cq = tid & 15, pg = tid >> 4;
-    int ph[PPT], pw[PPT];
+    int poff[PPT];
+    unsigned pmask[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        int p = pix0 + pg + 16 * i;
+        const int p = pix0 + pg + 16 * i;
+        poff[i] = 0;
+        pmask[i] = 0u;
         if (p < L) {
-            int ho = p / a.Wo;
-            ph[i] = ho * a.stride - a.pad;
-            pw[i] = (p - ho * a.Wo) * a.stride - a.pad;
-        } else {
-            ph[i] = -0x10000;
-            pw[i] = -0x10000;
+            const int ho = p / a.Wo;
+            const int h0 = ho * a.stride - a.pad, w0 = (p - ho * a.Wo) * a.stride - a.pad;
+            poff[i] = (h0 * a.W + w0) * a.in_ld + cq * 4;
+            for (int kh = 0; kh < a.ks; ++kh)
+                for (int kw = 0; kw < a.ks; ++kw)
+                    if (h0 + kh >= 0 && h0 + kh < a.H && w0 + kw >= 0 && w0 + kw < a.W) pmask[i] |= 1u << (kh * a.ks + kw);
         }
     }
 
     f32x4 xr[PPT];
     i32x4 wreg[WPT];
     f32x4 sr, rr;
+    unsigned vbits = 0;   // validity of this step's PPT pixels (bit i)
 
     auto load_step = [&](int kstep) {
         const int tap = kstep / cchunks, c0 = (kstep - tap * cchunks) << 6;
         const int kh = tap / a.ks, kw = tap - kh * a.ks;
+        const int toff = (kh * a.W + kw) * a.in_ld + c0;      // wave-uniform
         const int col = tap * a.Cin + c0 + cq * 4;
         sr = *reinterpret_cast<const f32x4 *>(a.s + col);
         rr = *reinterpret_cast<const f32x4 *>(a.rinv + col);
+        vbits = 0;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
-            const int hi = ph[i] + kh, wi = pw[i] + kw;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
-                v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)hi * a.W + wi) * a.in_ld + c0 + cq * 4);
-            xr[i] = v;
+            const bool ok = (pmask[i] >> tap) & 1u;
+            vbits |= ok ? (1u << i) : 0u;
+            const int off = ok ? poff[i] + toff : cq * 4;      // padding pixels read pixel 0 and are zeroed through sxv
+            xr[i] = *reinterpret_cast<const f32x4 *>(a.x + off);
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int item = tid + 256 * i;        // (row, 16-byte chunk)
-            const int row = item >> 2, ch = item & 3;
-            i32x4 v = (i32x4){0, 0, 0, 0};
-            if (oc0 + row < a.Cout)
-                v = *reinterpret_cast<const i32x4 *>(static_cast<const int8_t *>(a.w) + (size_t)(oc0 + row) * K +
-                                                      (size_t)kstep * 64 + ch * 16);
-            wreg[i] = v;
+            const int row = min(oc0 + (item >> 2), a.Cout - 1), ch = item & 3;
+            wreg[i] = *reinterpret_cast<const i32x4 *>(static_cast<const int8_t *>(a.w) + (size_t)row * K + (size_t)kstep * 64 + ch * 16);
         }
     };
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i)
-            *reinterpret_cast<int *>(Xbuf(buf) + (pg + 16 * i) * LD + cq * 4) = quant_pack4(xr[i], sr, rr, sx);
+            *reinterpret_cast<int *>(Xbuf(buf) + (pg + 16 * i) * LD + cq * 4) =
+                quant_pack4(xr[i], sr, rr, ((vbits >> i) & 1u) ? sx : 0.f);
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int item = tid + 256 * i;

@@ -88,9 +88,26 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
         __syncthreads();
         const unsigned int prefix = s_prefix;
         const unsigned int pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-        for (int i = threadIdx.x; i < L; i += blockDim.x) {
-            unsigned int key = key_of(i);
-            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1);
+        // heat-map scores cluster in a few bins: aggregate equal bins across the wave before touching the LDS histogram
+        for (int base = 0; base < L; base += blockDim.x) {
+            const int i = base + threadIdx.x;
+            unsigned int bin = 0xffffffffu;
+            if (i < L) {
+                const unsigned int key = key_of(i);
+                if ((key & pmask) == prefix) bin = (key >> shift) & 0xff;
+            }
+            if (pass >= 2) {   // low key bits are spread out: plain LDS atomics
+                if (bin != 0xffffffffu) atomicAdd(&hist[bin], 1);
+                continue;
+            }
+            u64 active = __ballot(bin != 0xffffffffu);
+            while (active) {
+                const int leader = __ffsll((long long)active) - 1;
+                const unsigned int lb = __shfl(bin, leader, 64);
+                const u64 same = __ballot(bin == lb);
+                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&hist[lb], (int)__popcll(same));
+                active &= ~same;
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {

@@ -157,16 +157,17 @@ __device__ __forceinline__ float block_max_1024(float v, float *sh) {
     return r;
 }
 
-// one block: smoothing scales + per-tensor activation scale
-__global__ __launch_bounds__(1024) void sq_scales_kernel(const float *__restrict__ pieces,
-                                                         const float *__restrict__ w_colmax, int Cin, int ntaps,
-                                                         TapMasks tm, float alpha, float qmax_a, float static_amax_x,
-                                                         float *__restrict__ s_out, float *__restrict__ r_out,
-                                                         float *__restrict__ scal) {
+// smoothing scales, one column per thread; the per-tensor activation amax max_j a_j / s_j is accumulated with one atomic
+// per block into a caller-zeroed slot
+__global__ __launch_bounds__(256) void sq_scales_kernel(const float *__restrict__ pieces,
+                                                        const float *__restrict__ w_colmax, int Cin, int ntaps,
+                                                        TapMasks tm, float alpha, float *__restrict__ s_out,
+                                                        float *__restrict__ r_out, float *__restrict__ amax_x_acc) {
     __shared__ float sh[16];
     const int K = Cin * ntaps;
-    float tmax = 0.f;
-    for (int j = threadIdx.x; j < K; j += blockDim.x) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    float t = 0.f;
+    if (j < K) {
         const int tap = j / Cin, c = j - tap * Cin;
         const unsigned mask = tm.m[tap];
         float a = 0.f;
@@ -183,34 +184,33 @@ __global__ __launch_bounds__(1024) void sq_scales_kernel(const float *__restrict
         }
         s_out[j] = s;
         r_out[j] = __fdiv_rn(1.0f, s);
-        tmax = fmaxf(tmax, fabsf(__fdiv_rn(a, s)));
+        t = fabsf(__fdiv_rn(a, s));
     }
-    float amax_x = block_max_1024(tmax, sh);
-    if (static_amax_x > 0.f) amax_x = static_amax_x;
-    if (threadIdx.x == 0) {
-        const float eps = 1.0f / (float)(1 << 24);
-        float sx = __fdiv_rn(qmax_a, amax_x), dv = sx;
-        if (amax_x <= eps) { sx = 0.f; dv = 1.f; }
-        scal[0] = sx;
-        scal[1] = amax_x;
-        scal[2] = __fdiv_rn(1.0f, dv);
-    }
+    const float m = block_max_1024(t, sh);
+    if (threadIdx.x == 0 && m > 0.f && m > *amax_x_acc) aq3d_atomic_max_pos(amax_x_acc, m);
 }
 
 // one block per output channel: W' = W * s, per-row amax, int8 codes, combined dequant multiplier
 __global__ __launch_bounds__(256) void sq_weights_kernel(const float *__restrict__ weight, const float *__restrict__ s,
                                                          int K, float qmax_w, const float *__restrict__ static_amax_w,
-                                                         const float *__restrict__ scal, int8_t *__restrict__ wq,
+                                                         const float *__restrict__ amax_x_acc, float static_amax_x,
+                                                         float qmax_a, float *__restrict__ scal, int8_t *__restrict__ wq,
                                                          float *__restrict__ out_mul, float *__restrict__ amax_w_out) {
     __shared__ float sh[16];
     const int oc = blockIdx.x;
+    const float eps = 1.0f / (float)(1 << 24);
+    // per-tensor activation scale (every block derives it; block 0 publishes it for the conv kernel)
+    const float amax_x = static_amax_x > 0.f ? static_amax_x : *amax_x_acc;
+    float sx = __fdiv_rn(qmax_a, amax_x), dvx = sx;
+    if (amax_x <= eps) { sx = 0.f; dvx = 1.f; }
+    const float inv_sx = __fdiv_rn(1.0f, dvx);
+    if (oc == 0 && threadIdx.x == 0) { scal[0] = sx; scal[1] = amax_x; scal[2] = inv_sx; }
     const float *wrow = weight + (size_t)oc * K;
     float mx = 0.f;
     for (int j = threadIdx.x; j < K; j += 256) mx = fmaxf(mx, fabsf(__fmul_rn(wrow[j], s[j])));
     float amax = block_max_1024(mx, sh);
     if (threadIdx.x == 0) amax_w_out[oc] = amax;   // dynamic per-oc amax of W*s (what a max calibrator collects)
     if (static_amax_w) amax = static_amax_w[oc];
-    const float eps = 1.0f / (float)(1 << 24);
     float sw = __fdiv_rn(qmax_w, amax), dv = sw;
     if (amax <= eps) { sw = 0.f; dv = 1.f; }
     for (int j = threadIdx.x; j < K; j += 256) {
@@ -218,14 +218,15 @@ __global__ __launch_bounds__(256) void sq_weights_kernel(const float *__restrict
         q = fminf(fmaxf(q, -qmax_w - 1.f), qmax_w);
         wq[(size_t)oc * K + j] = (int8_t)(int)q;
     }
-    if (threadIdx.x == 0) out_mul[oc] = __fmul_rn(scal[2], __fdiv_rn(1.0f, dv));
+    if (threadIdx.x == 0) out_mul[oc] = __fmul_rn(inv_sx, __fdiv_rn(1.0f, dv));
 }
 
 extern "C" int aq3d_sq_prep(const float *pieces, const float *weight, const float *w_colmax,
                             const aq3d_conv2d_geom *g, float alpha, int32_t w_bits, int32_t a_bits,
-                            float static_amax_x, const float *static_amax_w, void *params, void *stream_) {
+                            float static_amax_x, const float *static_amax_w, float *amax_x_acc, void *params,
+                            void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    AQ3D_REQUIRE(pieces && weight && g && params, "aq3d_sq_prep: null argument");
+    AQ3D_REQUIRE(pieces && weight && g && params && amax_x_acc, "aq3d_sq_prep: null argument");
     AQ3D_REQUIRE(alpha < 0.f || w_colmax, "aq3d_sq_prep: w_colmax needed when smoothing is on");
     AQ3D_REQUIRE(g->ksize == 1 || g->ksize == 3, "aq3d_sq_prep: ksize=%d", g->ksize);
     AQ3D_REQUIRE(g->stride >= 1 && g->pad >= 0 && g->H >= 3 && g->W >= 3, "aq3d_sq_prep: bad geometry");
@@ -243,10 +244,10 @@ extern "C" int aq3d_sq_prep(const float *pieces, const float *weight, const floa
     int8_t *wq = (int8_t *)(base + l.wq);
     const int ntaps = g->ksize * g->ksize, K = g->Cin * ntaps;
     const float qa = (float)((1 << (a_bits - 1)) - 1), qw = (float)((1 << (w_bits - 1)) - 1);
-    hipLaunchKernelGGL(sq_scales_kernel, dim3(1), dim3(1024), 0, stream, pieces, w_colmax, g->Cin, ntaps, tm, alpha, qa,
-                       static_amax_x, s, r, scal);
-    hipLaunchKernelGGL(sq_weights_kernel, dim3(g->Cout), dim3(256), 0, stream, weight, s, K, qw, static_amax_w, scal, wq,
-                       mul, amaxw);
+    hipLaunchKernelGGL(sq_scales_kernel, dim3(aq3d_div_up(K, 256)), dim3(256), 0, stream, pieces, w_colmax, g->Cin, ntaps, tm,
+                       alpha, s, r, amax_x_acc);
+    hipLaunchKernelGGL(sq_weights_kernel, dim3(g->Cout), dim3(256), 0, stream, weight, s, K, qw, static_amax_w, amax_x_acc,
+                       static_amax_x, qa, scal, wq, mul, amaxw);
     AQ3D_CHECK_LAUNCH("aq3d_sq_prep");
     return AQ3D_OK;
 }

@@ -307,6 +307,7 @@ class Engine:
                         self._pieces[pkey] = self.arena.alloc(16 * cin)
                     rec["pieces"] = self._pieces[pkey]
                     rec["params"] = torch.empty((ops.sq_param_bytes(cin, g.Cout, k),), dtype=torch.uint8, device=dev)
+                    rec["amax_x_acc"] = self.arena.alloc(1)
                     wq_, iq_ = mod._weight_quantizer, mod._input_quantizer
                     rec["w_bits"], rec["a_bits"] = wq_.num_bits, iq_.num_bits
                     rec["static_x"] = float(iq_.amax.reshape(-1)[0]) if iq_.amax is not None else 0.0
@@ -544,7 +545,7 @@ class Engine:
                         ops.piece_absmax(x[b], g.H, g.W, g.Cin, g.in_ld, pieces)
             with _Timed(self, "sq_prep"):
                 ops.sq_prep(pieces, rec["weight"], rec["w_colmax"], g, rec["alpha"], rec["params"], rec["w_bits"],
-                            rec["a_bits"], rec["static_x"], rec["static_w"])
+                            rec["a_bits"], rec["static_x"], rec["static_w"], self.arena.view(rec["amax_x_acc"]))
             with _Timed(self, "conv2d_i8"):
                 for b in range(B):
                     ops.conv2d_i8(x[b], rec["params"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b])

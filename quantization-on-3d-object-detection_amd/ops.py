@@ -236,14 +236,17 @@ def sq_param_bytes(Cin, Cout, ksize):
 
 
 def sq_prep(pieces, weight_k, w_colmax, g, alpha, params=None, w_bits=8, a_bits=8, static_amax_x=0.0,
-            static_amax_w=None):
-    """weight_k f32 [Cout, K] with K ordered (kh, kw, c). → params block (uint8 tensor)."""
+            static_amax_w=None, amax_x_acc=None):
+    """weight_k f32 [Cout, K] with K ordered (kh, kw, c). → params block (uint8 tensor).
+    amax_x_acc: f32 [1] accumulator zeroed once per frame by the caller (a fresh zero tensor when omitted)."""
     L = _lib.load()
     if params is None:
         params = torch.empty((sq_param_bytes(g.Cin, g.Cout, g.ksize),), dtype=torch.uint8, device=pieces.device)
+    if amax_x_acc is None:
+        amax_x_acc = torch.zeros((1,), dtype=f32, device=pieces.device)
     check(L.aq3d_sq_prep(_p(pieces), _p(weight_k), _p(w_colmax), ctypes.byref(g), float(alpha if alpha is not None else -1.0),
-                         int(w_bits), int(a_bits), float(static_amax_x), _p(static_amax_w), _p(params), _stream()),
-          "aq3d_sq_prep")
+                         int(w_bits), int(a_bits), float(static_amax_x), _p(static_amax_w), _p(amax_x_acc), _p(params),
+                         _stream()), "aq3d_sq_prep")
     return params
 
 
