@@ -155,12 +155,12 @@ enum { AQ3D_FLAG_RELU = 1 };
  *   y        += residual[m,o]                                              (may be NULL)
  *   y         = max(y, 0) if flags & AQ3D_FLAG_RELU
  *   absmax_out[o] = max(absmax_out[o], |y[m,o]|) over m                    (may be NULL; caller zeroes it)
- * Cin in {4..128} padded to a multiple of 4 by the caller (Cin_pad); Cout in {16,32,64,128}.
+ * cap_in = rows of the feats_in buffer (bounds of the hardware-checked loads of the f16-split path).
  */
 int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant,
                 const void *weight, int32_t w_mode, const float *w_dequant,
                 const float *bias, const float *post_scale, const float *post_shift,
-                const float *residual, const int32_t *nbr, const int32_t *count_out, int32_t cap_out,
+                const float *residual, const int32_t *nbr, const int32_t *count_out, int32_t cap_out, int32_t cap_in,
                 int32_t cin, int32_t cout, int32_t kvol, int32_t flags,
                 float *feats_out, float *absmax_out, void *stream);
 

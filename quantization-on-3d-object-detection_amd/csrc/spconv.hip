@@ -249,16 +249,16 @@ int aq3d_spconv_i8_dispatch(const int8_t *feats_in, const float *act_dequant, co
                             const float *bias, const float *post_scale, const float *post_shift, const float *residual,
                             const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
                             float *feats_out, float *absmax_out, hipStream_t stream);
-int aq3d_spconv_split_dispatch(const void *feats_split, const void *weight_f16, const float *w_dequant, const float *bias,
-                               const float *post_scale, const float *post_shift, const float *residual, const int *nbr,
-                               const int *count_out, int cap_out, int cin, int cout, int kvol, int relu, float *feats_out,
-                               float *absmax_out, hipStream_t stream);
+int aq3d_spconv_split_dispatch(const void *feats_split, unsigned feats_bytes, const void *weight_f16, const float *w_dequant,
+                               const float *bias, const float *post_scale, const float *post_shift, const float *residual,
+                               const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
+                               float *feats_out, float *absmax_out, hipStream_t stream);
 
 extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
                            int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
                            const float *post_shift, const float *residual, const int32_t *nbr,
-                           const int32_t *count_out, int32_t cap_out, int32_t cin, int32_t cout, int32_t kvol,
-                           int32_t flags, float *feats_out, float *absmax_out, void *stream_) {
+                           const int32_t *count_out, int32_t cap_out, int32_t cap_in, int32_t cin, int32_t cout,
+                           int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AQ3D_REQUIRE(feats_in && weight && nbr && count_out && feats_out, "aq3d_spconv: null argument");
     AQ3D_REQUIRE(cap_out > 0 && kvol >= 1 && kvol <= 27, "aq3d_spconv: cap_out=%d kvol=%d", cap_out, kvol);
@@ -269,9 +269,10 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
     if (act_mode == AQ3D_ACT_F16SPLIT || w_mode == AQ3D_W_F16) {
         AQ3D_REQUIRE(act_mode == AQ3D_ACT_F16SPLIT && w_mode == AQ3D_W_F16 && w_dequant,
                      "aq3d_spconv: f16-split activations go with f16 weight codes (+ w_dequant)");
-        return aq3d_spconv_split_dispatch(feats_in, weight, w_dequant, bias, post_scale, post_shift, residual, nbr, count_out,
-                                          cap_out, cin, cout, kvol, (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out,
-                                          stream);
+        AQ3D_REQUIRE(cap_in > 0 && (int64_t)cap_in * cin * 4 < (int64_t)0xfffffff0, "aq3d_spconv: cap_in=%d needed (and < 4 GiB of features) for the f16-split path", cap_in);
+        return aq3d_spconv_split_dispatch(feats_in, (unsigned)((int64_t)cap_in * cin * 4), weight, w_dequant, bias, post_scale,
+                                          post_shift, residual, nbr, count_out, cap_out, cin, cout, kvol,
+                                          (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, stream);
     }
     if (act_mode == AQ3D_ACT_I8 && w_mode == AQ3D_W_I8) {
         static const bool force_f32 = getenv("AQ3D_SPCONV_F32MFMA") != nullptr;   // A/B switch: exact-f32 MFMA path

@@ -183,7 +183,8 @@ def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequan
     assert weight.shape == (kvol, cout, cin), (tuple(weight.shape), (kvol, cout, cin))
     y = out if out is not None else torch.empty((cap_out, cout), dtype=f32, device=nbr.device)
     check(L.aq3d_spconv(_p(feats_in), act_mode, _p(act_dequant), _p(weight), w_mode, _p(w_dequant), _p(bias),
-                        _p(post_scale), _p(post_shift), _p(residual), _p(nbr), _p(count_out), cap_out, cin, cout, kvol,
+                        _p(post_scale), _p(post_shift), _p(residual), _p(nbr), _p(count_out), cap_out, int(feats_in.shape[0]),
+                        cin, cout, kvol,
                         FLAG_RELU if relu else 0, _p(y), _p(absmax_out), _stream()), "aq3d_spconv")
     return y
 
