@@ -24,7 +24,7 @@ import torch  # noqa: E402
 
 N_POINTS, N_VOXELS, N_FRAMES = 150000, 30000, 8
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
-MFMA_PEAK_TOPS = {"i8": 5000.0, "f32": 157.3}   # dense peaks: int8 = 2x bf16 (2.5 PF); f32-input MFMA = vector rate
+MFMA_PEAK_TOPS = {"i8": 5000.0, "f16": 2500.0, "f32": 157.3}   # dense peaks: int8 = 2x f16/bf16 (2.5 PF); f32 MFMA = vector rate
 
 
 def build(cfg_path, dev):
@@ -82,6 +82,8 @@ def kernel_work(eng, cat):
             m_out, m_in = int(lv_out["count"].item()), int(lv_in["count"].item())
             nbr = eng._nbr_of(r["nbr"])[:m_out]
             pairs = int((nbr >= 0).sum().item())
+            # algorithmic activation bytes: the int8 code of the quantised input (1 B) or fp32 (4 B) — what the layer needs,
+            # not what the chosen staging format (fp16 hi/lo pair) moves
             abytes = 1 if r["quant"] is not None and r["quant"]["on"] and r["quant"]["use_codes"] else 4
             wbytes = 1 if r["w_dequant"] is not None else 4
             ops += 2 * pairs * r["cin"] * r["cout"]
@@ -176,9 +178,22 @@ def main():
                 roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TOPS["f32"], "unit": "TFLOP/s",
                         "frac": ach / MFMA_PEAK_TOPS["f32"], "traffic": None}
             else:
-                ach = byts / max(n_launch, 1) / avg_launch_s / 1e9 if n_launch else 0.0
-                roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                        "traffic": None}
+                # sparse conv family: bound by whichever roof its arithmetic intensity puts it under
+                gbs = byts / max(n_launch, 1) / avg_launch_s / 1e9 if n_launch else 0.0
+                tfs = ops / max(n_launch, 1) / avg_launch_s / 1e12 if n_launch else 0.0
+                ridge = MFMA_PEAK_TOPS["f16"] * 1e12 / (HBM_PEAK_GBS * 1e9)          # FLOP per byte where the roofs meet
+                if byts > 0 and ops / byts > ridge:
+                    roof = {"bound": "mfma", "achieved": tfs, "peak": MFMA_PEAK_TOPS["f16"], "unit": "TFLOP/s",
+                            "frac": tfs / MFMA_PEAK_TOPS["f16"], "traffic": None, "hbm_GBps_algorithmic": gbs}
+                else:
+                    roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "traffic": None, "useful_TFLOPs": tfs}
+                roof["intensity_flop_per_byte"] = ops / byts if byts else None
+            try:      # HBM bytes per launch measured with rocprofv3 --pmc in a separate run (profiles/pmc_traffic.json)
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                    roof["traffic"] = json.load(f).get(dominant, None)
+            except Exception:
+                pass
             roof.update({"kernel": dominant, "launches_per_frame": n_launch, "avg_launch_us": avg_launch_s * 1e6,
                          "ms_per_frame": per_frame_ms})
         out = {

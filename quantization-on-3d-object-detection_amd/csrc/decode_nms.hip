@@ -68,8 +68,10 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
     int *hist = reinterpret_cast<int *>(sel + Kpad);       // [256]
     int *sh = hist + 256;                                  // [16]
     unsigned int *keys_s = reinterpret_cast<unsigned int *>(sh + 16);   // [L] score bit patterns (when they fit in LDS)
+    constexpr int TIE_CAP = 512;
     __shared__ unsigned int s_prefix;
-    __shared__ int s_remaining, s_fill;
+    __shared__ int s_remaining, s_fill, s_ties;
+    __shared__ unsigned int tie_idx[TIE_CAP];
     const int cls = blockIdx.x;
     const float *col = hm + cls;
     const int Keff = K < L ? K : L;
@@ -88,7 +90,6 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
         __syncthreads();
         const unsigned int prefix = s_prefix;
         const unsigned int pmask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
-        // heat-map scores cluster in a few bins: aggregate equal bins across the wave before touching the LDS histogram
         for (int base = 0; base < L; base += blockDim.x) {
             const int i = base + threadIdx.x;
             unsigned int bin = 0xffffffffu;
@@ -96,10 +97,11 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
                 const unsigned int key = key_of(i);
                 if ((key & pmask) == prefix) bin = (key >> shift) & 0xff;
             }
-            if (pass >= 2) {   // low key bits are spread out: plain LDS atomics
+            if (pass > 0) {   // lower key bits are spread out: plain LDS atomics
                 if (bin != 0xffffffffu) atomicAdd(&hist[bin], 1);
                 continue;
             }
+            // top byte of a heat-map score: nearly every key shares it → one atomic per wave and distinct value
             u64 active = __ballot(bin != 0xffffffffu);
             while (active) {
                 const int leader = __ffsll((long long)active) - 1;
@@ -110,42 +112,73 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int rem = s_remaining, b = 255;
-            for (; b > 0; --b) {
-                if (hist[b] >= rem) break;
-                rem -= hist[b];
+        // suffix sums of the 256 bins by the first 256 threads (4 waves): bin b is the pivot iff
+        // sum(hist[b+1..255]) < rem <= sum(hist[b..255])
+        {
+            int v = 0, incl = 0;
+            if (threadIdx.x < 256) {
+                v = hist[255 - threadIdx.x];              // reversed: prefix sums from the top bin down
+                incl = v;
+                const int lane = threadIdx.x & 63;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    int t = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += t;
+                }
+                if (lane == 63) sh[threadIdx.x >> 6] = incl;
             }
-            s_prefix = prefix | ((unsigned int)b << shift);
-            s_remaining = rem;  // how many keys equal to the final prefix are still needed
+            __syncthreads();
+            if (threadIdx.x < 256) {
+                int basev = 0;
+                for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) basev += sh[w];
+                incl += basev;                             // keys in bins >= (255 - tid)
+                const int rem = s_remaining;
+                if (incl >= rem && incl - v < rem) {       // exactly one thread
+                    s_prefix = prefix | ((unsigned int)(255 - threadIdx.x) << shift);
+                    s_remaining = rem - (incl - v);
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     const unsigned int T = s_prefix;
     const int need_ties = s_remaining;
     for (int i = threadIdx.x; i < Kpad; i += blockDim.x) sel[i] = 0ull;
-    if (threadIdx.x == 0) s_fill = 0;
+    if (threadIdx.x == 0) { s_fill = 0; s_ties = 0; }
     __syncthreads();
-    // keys > T in any order (sorted afterwards)
+    // keys > T in any order (sorted afterwards); keys == T: collect up to TIE_CAP indices
     for (int i = threadIdx.x; i < L; i += blockDim.x) {
-        unsigned int key = key_of(i);
+        const unsigned int key = key_of(i);
         if (key > T) {
             int pos = atomicAdd(&s_fill, 1);
             sel[pos] = ((u64)key << 32) | (u64)(0xffffffffu - (unsigned int)i);
+        } else if (key == T) {
+            int pos = atomicAdd(&s_ties, 1);
+            if (pos < TIE_CAP) tie_idx[pos] = (unsigned int)i;
         }
     }
     __syncthreads();
-    // keys == T in ascending index order until need_ties are taken (ordered compaction, 1024 pixels per round)
-    int taken = 0;
-    const int gt = s_fill;
-    for (int base = 0; base < L && taken < need_ties; base += blockDim.x) {
-        const int i = base + threadIdx.x;
-        int f = 0;
-        if (i < L) f = (key_of(i) == T) ? 1 : 0;
-        int tot;
-        int pos = block_scan_excl_1024(f, sh, &tot);
-        if (f && taken + pos < need_ties) sel[gt + taken + pos] = ((u64)T << 32) | (u64)(0xffffffffu - (unsigned int)i);
-        taken += tot;
+    const int gt = s_fill, nties = s_ties;
+    if (nties <= TIE_CAP) {
+        // few ties (the normal case): rank each tie by its index, the need_ties smallest go in
+        for (int t = threadIdx.x; t < nties; t += blockDim.x) {
+            const unsigned int mine_i = tie_idx[t];
+            int rank = 0;
+            for (int q = 0; q < nties; ++q) rank += tie_idx[q] < mine_i;
+            if (rank < need_ties) sel[gt + rank] = ((u64)T << 32) | (u64)(0xffffffffu - mine_i);
+        }
+    } else {
+        // many equal scores (saturated / constant heat map): ordered compaction, 1024 pixels per round
+        int taken = 0;
+        for (int base = 0; base < L && taken < need_ties; base += blockDim.x) {
+            const int i = base + threadIdx.x;
+            int f = 0;
+            if (i < L) f = (key_of(i) == T) ? 1 : 0;
+            int tot;
+            int pos = block_scan_excl_1024(f, sh, &tot);
+            if (f && taken + pos < need_ties) sel[gt + taken + pos] = ((u64)T << 32) | (u64)(0xffffffffu - (unsigned int)i);
+            taken += tot;
+        }
     }
     __syncthreads();
     bitonic_sort_desc(sel, Kpad);
