@@ -1,0 +1,114 @@
+#!/usr/bin/env python
+"""BASELINE configs[1]: ONE SubMConv3d 3x3x3 layer, int8 weights x per-channel-quantised activations, on the MI355X
+gather-GEMM kernel vs the CPU oracle — plus the voxel-count sweep (30 k → 1 M active voxels) that shows where the
+kernel sits against the HBM / MFMA roofs once launch latency stops dominating (SURVEY.md §7 hard part 1, §8d).
+
+    python benchmarks/subm_layer.py [--channels 16 64 128] [--voxels 30000 120000 480000 1000000] [--occupancy sheet|w150k]
+
+Prints one JSON line per (channels, voxels). Timed region: aq3d_quantize_rows (per-channel quantiser + fp16 split) +
+aq3d_spconv (fused bias/BN/ReLU epilogue) with the gather table already built, HIP events over `--iters` launches.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_GBS, F16_TFLOPS = 8000.0, 2500.0
+
+
+def occupancy(kind, m, seed=4):
+    """i32 [m, 4] active sites (b, z, y, x) inside a [41, 1504, 1504] grid."""
+    rng = np.random.default_rng(seed)
+    if kind == "sheet":          # contiguous ground sheet, 3 z-levels: ~13 of 27 neighbours active (LiDAR-like surfaces)
+        side = int(np.ceil(np.sqrt(m / 1.5)))
+        ys, xs = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+        base = np.stack([np.zeros(side * side, np.int64), np.full(side * side, 12), ys.ravel() + 8, xs.ravel() + 8], 1)
+        up = base[rng.random(len(base)) < 0.5].copy()
+        up[:, 1] = 13
+        idx = np.concatenate([base, up])[:m]
+        assert side + 16 <= 1504
+    else:                        # the W150k recipe: isolated cells, ~2 neighbours
+        from amdq3d.config import AttrDict, cfg_from_yaml_file
+        from amdq3d.synthetic import make_frame
+        from oracle import voxel as V
+        cfg = cfg_from_yaml_file("cfgs/waymo_models/centerpoint.yaml", AttrDict())
+        pr, vs = cfg.DATA_CONFIG.POINT_CLOUD_RANGE, [0.1, 0.1, 0.15]
+        pts = make_frame(seed, m * 5, m, pr, vs, [1504, 1504, 40])
+        _, c, _ = V.voxelize_mean(pts, pr, vs, 5, 10 ** 9)
+        idx = c.astype(np.int64)
+    idx = idx[rng.permutation(len(idx))]
+    return idx.astype(np.int32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--channels", type=int, nargs="+", default=[16, 64, 128])
+    ap.add_argument("--voxels", type=int, nargs="+", default=[30000, 120000, 480000, 1000000])
+    ap.add_argument("--occupancy", default="sheet")
+    ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle on the smallest size")
+    args = ap.parse_args()
+    from amdq3d import ops
+    from oracle import sparse as OS
+    dev = torch.device("cuda:0")
+    shape = [41, 1504, 1504]
+    for m_req in args.voxels:
+        idx = occupancy(args.occupancy, m_req)
+        m = len(idx)
+        cap = m
+        coords = torch.from_numpy(idx).to(dev)
+        count = torch.tensor([m], dtype=torch.int32, device=dev)
+        table = ops.hash_build(coords, count, shape)
+        nbr = ops.subm_neighbors(coords, count, shape, (3, 3, 3), table)
+        pairs = int((nbr >= 0).sum().item())
+        for C in args.channels:
+            g = torch.Generator().manual_seed(C)
+            x = torch.relu(torch.randn(m, C, generator=g)).to(dev)
+            w = torch.randn(C, 3, 3, 3, C, generator=g) / np.sqrt(13 * C)
+            wq, codes, wdiv = OS.qconv_weight(w.numpy(), 8)
+            wk = torch.from_numpy(np.ascontiguousarray(codes.reshape(C, 27, C).transpose(1, 0, 2))).to(dev)
+            w16 = wk.to(torch.float16)
+            wdq = torch.from_numpy((np.float32(1) / wdiv).astype(np.float32)).to(dev)
+            ps, pt = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+            amax = ops.absmax_cols(x, count)
+            out = torch.empty((cap, C), device=dev)
+            am_out = torch.zeros(C, device=dev)
+
+            def layer():
+                _, _, _, split = ops.quantize_rows(x, amax, count, want_codes=False, want_split=True)
+                return ops.spconv(split, w16, nbr, count, C, w_dequant=wdq, post_scale=ps, post_shift=pt, relu=True,
+                                  absmax_out=am_out, out=out)
+            for _ in range(5):
+                layer()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.iters):
+                layer()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            byts = m * C * 4 + m * C * 1 + m * C * 4 + 27 * C * C + m * 27 * 4      # fp32 in (quantiser) + codes + fp32 out + w + table
+            flops = 2.0 * pairs * C * C
+            rec = {"layer": "SubMConv3d 3x3x3 %d->%d int8-w x per-channel-quantised a" % (C, C), "occupancy": args.occupancy,
+                   "voxels": m, "pairs": pairs, "us_per_layer": us, "algorithmic_GBps": byts / us / 1e3,
+                   "frac_hbm": byts / us / 1e3 / HBM_GBS, "useful_TFLOPs": flops / us / 1e6,
+                   "frac_mfma_f16": flops / us / 1e6 / F16_TFLOPS, "voxels_per_s": m / us * 1e6}
+            if args.cpu and m_req == args.voxels[0]:
+                xa, _ = OS.qconv_act(x.cpu().numpy(), 8, cw=True)
+                nb = nbr.cpu().numpy()
+                t0 = time.time()
+                OS.gather_conv(xa, wq, nb)
+                rec["cpu_oracle_us"] = (time.time() - t0) * 1e6
+                rec["cpu_cores"] = int(torch.get_num_threads())
+            print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
