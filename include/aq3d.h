@@ -30,6 +30,9 @@
  *                            pcdet/models/dense_heads/center_head.py:22-29,75-82 (the layers left in fp32)
  *   aq3d_center_decode       centernet_utils.decode_bbox_from_heatmap, model_utils/centernet_utils.py:155-241
  *   aq3d_nms_rotated         iou3d_nms_utils.nms_gpu → iou3d_nms.cpp:137-183 + iou3d_nms_kernel.cu:295-339
+ *   aq3d_boxes_iou3d / aq3d_recall_counts
+ *                            iou3d_nms_utils.boxes_iou3d_gpu (iou3d_nms_utils.py:48-81, kernel iou3d_nms_kernel.cu:236-249) and
+ *                            the recall bookkeeping of Detector3DTemplate.generate_recall_record (detector3d_template.py:286-328)
  */
 #ifndef AQ3D_H
 #define AQ3D_H
@@ -259,6 +262,17 @@ int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_t *count, i
 int aq3d_gather_dets(const float *boxes, int32_t box_ld, const float *scores, const int32_t *labels,
                      const int32_t *class_map, const int32_t *keep, const int32_t *keep_count, int32_t cap,
                      float *boxes_out, float *scores_out, int64_t *labels_out, void *stream);
+
+/* ---------------------------------------------------------------- evaluation helpers (recall vs ground truth) ---- */
+
+/* iou_out f32 [n, m] = 3-D IoU (rotated BEV overlap x height overlap) of boxes_a [n, lda] vs boxes_b [m, ldb],
+ * first 7 columns (x, y, z, dx, dy, dz, heading). */
+int aq3d_boxes_iou3d(const float *boxes_a, int32_t n, int32_t lda, const float *boxes_b, int32_t m, int32_t ldb,
+                     float *iou_out, void *stream);
+
+/* counts_out i32 [n_thresh] += number of columns j of iou [n, m] whose maximum over the rows exceeds thresholds[t]. */
+int aq3d_recall_counts(const float *iou, int32_t n, int32_t m, const float *thresholds, int32_t n_thresh,
+                       int32_t *counts_out, void *stream);
 
 #ifdef __cplusplus
 }

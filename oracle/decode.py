@@ -29,6 +29,7 @@ def _lib():
         L = ctypes.CDLL(path)
         fp = ctypes.POINTER(ctypes.c_float)
         L.oracle_iou_bev_matrix.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, fp]
+        L.oracle_overlap_bev_matrix.argtypes = [fp, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, ctypes.c_int, fp]
         L.oracle_nms.argtypes = [fp, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.POINTER(ctypes.c_int)]
         L.oracle_nms.restype = ctypes.c_int
         _LIB = L
@@ -46,6 +47,21 @@ def iou_bev(boxes_a, boxes_b):
     if a.shape[0] and b.shape[0]:
         _lib().oracle_iou_bev_matrix(_fptr(a), a.shape[0], a.shape[1], _fptr(b), b.shape[0], b.shape[1], _fptr(out))
     return out
+
+
+def boxes_iou3d(boxes_a, boxes_b):
+    """pcdet/ops/iou3d_nms/iou3d_nms_utils.py:48-81 — BEV overlap x height overlap / union volume."""
+    a = np.ascontiguousarray(boxes_a, dtype=np.float32)
+    b = np.ascontiguousarray(boxes_b, dtype=np.float32)
+    ov = np.zeros((a.shape[0], b.shape[0]), dtype=np.float32)
+    if a.shape[0] and b.shape[0]:
+        _lib().oracle_overlap_bev_matrix(_fptr(a), a.shape[0], a.shape[1], _fptr(b), b.shape[0], b.shape[1], _fptr(ov))
+    a_max, a_min = (a[:, 2] + a[:, 5] / 2)[:, None], (a[:, 2] - a[:, 5] / 2)[:, None]
+    b_max, b_min = (b[:, 2] + b[:, 5] / 2)[None, :], (b[:, 2] - b[:, 5] / 2)[None, :]
+    ov_h = np.clip(np.minimum(a_max, b_max) - np.maximum(a_min, b_min), 0, None)
+    ov3d = ov * ov_h
+    va, vb = (a[:, 3] * a[:, 4] * a[:, 5])[:, None], (b[:, 3] * b[:, 4] * b[:, 5])[None, :]
+    return (ov3d / np.clip(va + vb - ov3d, 1e-6, None)).astype(np.float32)
 
 
 def nms_sorted(boxes, thresh):

@@ -92,6 +92,12 @@ float oracle_iou_bev(const float *a, const float *b) {
     return ov / fmaxf(sa + sb - ov, EPS);
 }
 
+/* overlap[n, m] (rotated BEV intersection area) between boxes_a [n, lda] and boxes_b [m, ldb]. */
+void oracle_overlap_bev_matrix(const float *a, int n, int lda, const float *b, int m, int ldb, float *ov) {
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < m; j++) ov[(size_t)i * m + j] = oracle_box_overlap(a + (size_t)i * lda, b + (size_t)j * ldb);
+}
+
 /* iou[n, m] between boxes_a [n, lda] and boxes_b [m, ldb] (first 7 columns used). */
 void oracle_iou_bev_matrix(const float *a, int n, int lda, const float *b, int m, int ldb, float *iou) {
     for (int i = 0; i < n; i++)

@@ -518,3 +518,57 @@ extern "C" int aq3d_gather_dets(const float *boxes, int32_t box_ld, const float 
     AQ3D_CHECK_LAUNCH("aq3d_gather_dets");
     return AQ3D_OK;
 }
+
+// ------------------------------------------------------------------ 3-D IoU matrix + recall counts
+__global__ __launch_bounds__(256) void boxes_iou3d_kernel(const float *__restrict__ A, int n, int lda,
+                                                          const float *__restrict__ B, int m, int ldb,
+                                                          float *__restrict__ out) {
+    const long long total = (long long)n * m;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const int i = (int)(t / m), j = (int)(t - (long long)i * m);
+        float a[7], b[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { a[k] = A[(size_t)i * lda + k]; b[k] = B[(size_t)j * ldb + k]; }
+        // iou3d_nms_utils.py:58-79 — torch ops there, same order here
+        const float a_max = a[2] + a[5] / 2, a_min = a[2] - a[5] / 2, b_max = b[2] + b[5] / 2, b_min = b[2] - b[5] / 2;
+        const float ov_bev = rotated_overlap(a, b);
+        const float ov_h = fmaxf(fminf(a_max, b_max) - fmaxf(a_min, b_min), 0.f);
+        const float ov3d = ov_bev * ov_h;
+        const float va = a[3] * a[4] * a[5], vb = b[3] * b[4] * b[5];
+        out[t] = ov3d / fmaxf(va + vb - ov3d, 1e-6f);
+    }
+}
+
+extern "C" int aq3d_boxes_iou3d(const float *boxes_a, int32_t n, int32_t lda, const float *boxes_b, int32_t m, int32_t ldb,
+                                float *iou_out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(n >= 0 && m >= 0 && lda >= 7 && ldb >= 7, "aq3d_boxes_iou3d: bad sizes n=%d m=%d lda=%d ldb=%d", n, m, lda, ldb);
+    if (n == 0 || m == 0) return AQ3D_OK;
+    AQ3D_REQUIRE(boxes_a && boxes_b && iou_out, "aq3d_boxes_iou3d: null argument");
+    hipLaunchKernelGGL(boxes_iou3d_kernel, dim3(aq3d_grid((int64_t)n * m, 256)), dim3(256), 0, stream, boxes_a, n, lda, boxes_b, m,
+                       ldb, iou_out);
+    AQ3D_CHECK_LAUNCH("aq3d_boxes_iou3d");
+    return AQ3D_OK;
+}
+
+__global__ __launch_bounds__(256) void recall_counts_kernel(const float *__restrict__ iou, int n, int m,
+                                                            const float *__restrict__ thr, int nt, int *counts) {
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < m; j += gridDim.x * 256) {
+        float mx = -1.f;
+        for (int i = 0; i < n; ++i) mx = fmaxf(mx, iou[(size_t)i * m + j]);
+        for (int t = 0; t < nt; ++t)
+            if (mx > thr[t]) atomicAdd(&counts[t], 1);
+    }
+}
+
+extern "C" int aq3d_recall_counts(const float *iou, int32_t n, int32_t m, const float *thresholds, int32_t n_thresh,
+                                  int32_t *counts_out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(n >= 0 && m >= 0 && n_thresh >= 1, "aq3d_recall_counts: bad sizes");
+    if (n == 0 || m == 0) return AQ3D_OK;
+    AQ3D_REQUIRE(iou && thresholds && counts_out, "aq3d_recall_counts: null argument");
+    hipLaunchKernelGGL(recall_counts_kernel, dim3(aq3d_grid(m, 256)), dim3(256), 0, stream, iou, n, m, thresholds, n_thresh,
+                       counts_out);
+    AQ3D_CHECK_LAUNCH("aq3d_recall_counts");
+    return AQ3D_OK;
+}

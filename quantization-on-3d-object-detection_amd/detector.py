@@ -225,9 +225,34 @@ class CenterPoint(Detector3DTemplate):
 
     @staticmethod
     def generate_recall_record(box_preds, recall_dict, batch_index, data_dict=None, thresh_list=None):
+        """detector3d_template.py:286-328 for single-stage detectors (no 'rois'): recalled ground-truth boxes per
+        3-D-IoU threshold, accumulated over the batch."""
         if "gt_boxes" not in data_dict:
             return recall_dict
-        raise NotImplementedError("recall bookkeeping against gt_boxes needs the 3-D IoU kernels (SURVEY.md §8f rank 3)")
+        from . import ops
+        gt_boxes = data_dict["gt_boxes"][batch_index]
+        if recall_dict.__len__() == 0:
+            recall_dict = {"gt": 0}
+            for cur_thresh in thresh_list:
+                recall_dict["roi_%s" % (str(cur_thresh))] = 0
+                recall_dict["rcnn_%s" % (str(cur_thresh))] = 0
+        cur_gt = gt_boxes if torch.is_tensor(gt_boxes) else torch.as_tensor(gt_boxes)
+        gt_host = cur_gt.detach().float().cpu()
+        k = gt_host.shape[0] - 1
+        while k >= 0 and float(gt_host[k].sum()) == 0:          # trailing zero rows are batch padding
+            k -= 1
+        n_gt = k + 1
+        if n_gt > 0:
+            if box_preds.shape[0] > 0:
+                gt_dev = cur_gt[:n_gt, 0:7].to(box_preds.device, torch.float32).contiguous()
+                iou = ops.boxes_iou3d(box_preds[:, 0:7].contiguous(), gt_dev)
+                thr = torch.tensor([float(t) for t in thresh_list], dtype=torch.float32, device=box_preds.device)
+                counts = torch.zeros((len(thresh_list),), dtype=torch.int32, device=box_preds.device)
+                ops.recall_counts(iou, thr, counts)
+                for t, c in zip(thresh_list, counts.cpu().tolist()):
+                    recall_dict["rcnn_%s" % str(t)] += int(c)
+            recall_dict["gt"] += n_gt
+        return recall_dict
 
 
 DETECTORS = {"CenterPoint": CenterPoint}

@@ -369,3 +369,24 @@ def sq_param_views(params, Cin, Cout, ksize):
         "scal": params[o_scal:o_scal + 32].view(f32),     # [sx, amax_x, 1/sx, ...]
         "wq": params[o_wq:o_wq + Cout * K].view(torch.int8).view(Cout, K),
     }
+
+
+# ------------------------------------------------------------------ evaluation helpers
+def boxes_iou3d(boxes_a, boxes_b):
+    """boxes_iou3d_gpu of the reference: f32 [n, m] 3-D IoU of boxes_a [n, >=7] vs boxes_b [m, >=7]."""
+    L = _lib.load()
+    boxes_a, boxes_b = boxes_a.contiguous(), boxes_b.contiguous()
+    n, m = boxes_a.shape[0], boxes_b.shape[0]
+    out = torch.zeros((n, m), dtype=f32, device=boxes_a.device)
+    check(L.aq3d_boxes_iou3d(_p(boxes_a) if n else None, n, boxes_a.shape[1], _p(boxes_b) if m else None, m, boxes_b.shape[1],
+                             _p(out) if n * m else None, _stream()), "aq3d_boxes_iou3d")
+    return out
+
+
+def recall_counts(iou, thresholds, counts):
+    """counts i32 [T] += #columns of iou whose max over rows exceeds thresholds[t]."""
+    L = _lib.load()
+    n, m = iou.shape
+    check(L.aq3d_recall_counts(_p(iou) if n * m else None, n, m, _p(thresholds), thresholds.numel(), _p(counts), _stream()),
+          "aq3d_recall_counts")
+    return counts

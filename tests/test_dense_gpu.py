@@ -208,3 +208,29 @@ def test_nms_empty_and_gather(dev):
     k = keep[:m].long()
     assert torch.equal(bo[:m], t[k]) and torch.equal(so[:m], scores[k])
     assert torch.equal(lo[:m], cmap[labels[k].long()].long() + 1)
+
+
+def test_boxes_iou3d_and_recall_record(dev):
+    """boxes_iou3d_gpu + generate_recall_record (detector3d_template.py:286-328) against the oracle."""
+    from amdq3d import ops
+    from amdq3d.detector import CenterPoint
+    a, b = _boxes(120, 7), _boxes(40, 8)
+    b[:15] = a[:15] + np.random.default_rng(0).normal(0, 0.05, (15, 7)).astype(np.float32)     # some well-matched pairs
+    ref = OD.boxes_iou3d(a, b)
+    got = ops.boxes_iou3d(torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5)
+    assert ops.boxes_iou3d(torch.zeros((0, 7), device=dev), torch.from_numpy(b).to(dev)).shape == (0, 40)
+    gt = np.zeros((2, 50, 8), np.float32)
+    gt[0, :40, :7] = b; gt[0, :40, 7] = 1
+    gt[1, :10, :7] = b[:10]; gt[1, :10, 7] = 2
+    data = {"gt_boxes": torch.from_numpy(gt).to(dev), "batch_size": 2}
+    rd = {}
+    preds = [torch.from_numpy(a).to(dev), torch.from_numpy(a[:30]).to(dev)]
+    for bi in range(2):
+        rd = CenterPoint.generate_recall_record(preds[bi], rd, bi, data, [0.3, 0.5, 0.7])
+    exp = {"gt": 50}
+    for t in (0.3, 0.5, 0.7):
+        exp["rcnn_%s" % t] = int((ref.max(axis=0) > t).sum()) + int((OD.boxes_iou3d(a[:30], b[:10]).max(axis=0) > t).sum())
+        exp["roi_%s" % t] = 0
+    assert rd == exp
+    assert CenterPoint.generate_recall_record(preds[0], {}, 0, {"batch_size": 1}, [0.3]) == {}
