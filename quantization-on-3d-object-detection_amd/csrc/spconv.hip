@@ -249,6 +249,10 @@ int aq3d_spconv_i8_dispatch(const int8_t *feats_in, const float *act_dequant, co
                             const float *bias, const float *post_scale, const float *post_shift, const float *residual,
                             const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
                             float *feats_out, float *absmax_out, hipStream_t stream);
+int aq3d_spconv_direct_dispatch(const void *feats_split, unsigned feats_bytes, const void *weight_f16, const float *w_dequant,
+                                const float *bias, const float *post_scale, const float *post_shift, const float *residual,
+                                const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
+                                float *feats_out, float *absmax_out, hipStream_t stream);
 int aq3d_spconv_split_dispatch(const void *feats_split, unsigned feats_bytes, const void *weight_f16, const float *w_dequant,
                                const float *bias, const float *post_scale, const float *post_shift, const float *residual,
                                const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
@@ -270,6 +274,12 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
         AQ3D_REQUIRE(act_mode == AQ3D_ACT_F16SPLIT && w_mode == AQ3D_W_F16 && w_dequant,
                      "aq3d_spconv: f16-split activations go with f16 weight codes (+ w_dequant)");
         AQ3D_REQUIRE(cap_in > 0 && (int64_t)cap_in * cin * 4 < (int64_t)0xfffffff0, "aq3d_spconv: cap_in=%d needed (and < 4 GiB of features) for the f16-split path", cap_in);
+        {
+            int rc = aq3d_spconv_direct_dispatch(feats_in, (unsigned)((int64_t)cap_in * cin * 4), weight, w_dequant, bias,
+                                                 post_scale, post_shift, residual, nbr, count_out, cap_out, cin, cout, kvol,
+                                                 (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, stream);
+            if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
+        }
         return aq3d_spconv_split_dispatch(feats_in, (unsigned)((int64_t)cap_in * cin * 4), weight, w_dequant, bias, post_scale,
                                           post_shift, residual, nbr, count_out, cap_out, cin, cout, kvol,
                                           (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, stream);
