@@ -213,16 +213,19 @@ int aq3d_sq_prep(const float *pieces, const float *weight, const float *w_colmax
                  float static_amax_x, const float *static_amax_w, float *amax_x_acc, void *params, void *stream);
 
 /* y = epilogue( int32 GEMM of quantised im2col(x) with quantised weights ) — SQConv2d.forward.
- *   epilogue: v = acc * out_mul[o] + bias[o]; y = v * post_scale[o] + post_shift[o]; relu. */
+ *   epilogue: v = acc * out_mul[o] + bias[o]; y = v * post_scale[o] + post_shift[o]; relu.
+ *   pieces_out (may be NULL): f32 [16, pieces_ld] piece abs-max accumulator of the OUTPUT tensor (same definition as
+ *   aq3d_piece_absmax over the output image, column out_coff + o), so that the next SmoothQuant conv needs no extra pass;
+ *   zeroed by the caller once per frame. */
 int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_conv2d_geom *g,
                    const float *bias, const float *post_scale, const float *post_shift,
-                   float *y, void *stream);
+                   float *y, float *pieces_out, int32_t pieces_ld, void *stream);
 
 /* fp32 conv / transposed conv (MFMA f32), weight f32 [Cout_total, K] with K ordered (kh, kw, c);
  * for deconv = d the weight rows are ordered (i, j, o): row = (i*d + j)*Cout + o. */
 int aq3d_conv2d_f32(const float *x, const float *weight, const aq3d_conv2d_geom *g,
                     const float *bias, const float *post_scale, const float *post_shift,
-                    float *y, void *stream);
+                    float *y, float *pieces_out, int32_t pieces_ld, void *stream);
 
 /* ---------------------------------------------------------------- head decode + NMS ----------- */
 

@@ -31,7 +31,11 @@ struct ConvArgs {
     float *y;
     int H, W, Cin, Cout, ks, stride, pad, Ho, Wo, in_ld, out_ld, out_coff, deconv, relu;
     int rows_total;         // GEMM rows: Cout (conv) or deconv*deconv*Cout
+    float *pieces_out;      // optional [16][pieces_ld] abs-max accumulator of the output image
+    int pieces_ld;
 };
+
+__device__ __forceinline__ int piece_cls(int i, int n) { return i == 0 ? 0 : (i == n - 1 ? 1 : 2 + (i & 1)); }
 
 // exact fp32 division x / s given r = RN(1/s): one Newton correction on the quotient (Markstein)
 __device__ __forceinline__ float div_by_scale(float x, float s, float r) {
@@ -70,6 +74,7 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvArgs a) {
     constexpr int WPT = BM / 64;  // 16-byte weight chunks per thread (BM*4 chunks / 256 threads)
     static_assert(BM >= 64, "BM >= 64");
     __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * LD];
+    __shared__ unsigned int pm[16 * BM];     // piece maxima of this workgroup's outputs (bit patterns of |v|, v >= 0)
     auto Wbuf = [&](int b) -> char * { return smem + b * (BM + BN) * LD; };
     auto Xbuf = [&](int b) -> char * { return smem + b * (BM + BN) * LD + BM * LD; };
 
@@ -81,6 +86,8 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvArgs a) {
     const int pix0 = blockIdx.x * BN;
     const int oc0 = blockIdx.y * BM;
     const int cchunks = a.Cin >> 6;
+    if (a.pieces_out)
+        for (int i = tid; i < 16 * BM; i += 256) pm[i] = 0u;      // ordered before its use by the K loop's barriers
     const int nk = a.ks * a.ks * cchunks;
     const float sx = a.scal[0];
 
@@ -197,6 +204,23 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvArgs a) {
                 v[r] = t;
             }
             *reinterpret_cast<f32x4 *>(a.y + (size_t)p * a.out_ld + a.out_coff + oc) = v;
+            if (a.pieces_out) {
+                const int ho = p / a.Wo;
+                const int pc = piece_cls(ho, a.Ho) * 4 + piece_cls(p - ho * a.Wo, a.Wo);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) atomicMax(&pm[pc * BM + (oc - oc0) + r], __float_as_uint(fabsf(v[r])));
+            }
+        }
+    }
+    if (a.pieces_out) {
+        __syncthreads();
+        for (int i = tid; i < 16 * BM; i += 256) {
+            const unsigned int v = pm[i];
+            const int pc = i / BM, oc = oc0 + i % BM;
+            if (v != 0u && oc < a.Cout) {
+                unsigned int *dst = reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc * a.pieces_ld + a.out_coff + oc;
+                if (v > *dst) atomicMax(dst, v);
+            }
         }
     }
 }
@@ -333,6 +357,14 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvArgs a) {
                 if (a.post_scale) t = __fadd_rn(__fmul_rn(t, a.post_scale[oc]), a.post_shift[oc]);
                 if (a.relu) t = fmaxf(t, 0.f);
                 a.y[opix * a.out_ld + a.out_coff + oc] = t;
+                if (a.pieces_out) {
+                    const int OW = d > 0 ? a.Wo * d : a.Wo, OH = d > 0 ? a.Ho * d : a.Ho;
+                    const int oh = (int)(opix / OW), ow = (int)(opix - (size_t)oh * OW);
+                    unsigned int *dst = reinterpret_cast<unsigned int *>(a.pieces_out) +
+                                        (size_t)(piece_cls(oh, OH) * 4 + piece_cls(ow, OW)) * a.pieces_ld + a.out_coff + oc;
+                    const unsigned int vb = __float_as_uint(fabsf(t));
+                    if (vb > *dst) atomicMax(dst, vb);
+                }
             }
         }
     }
@@ -350,17 +382,23 @@ static int fill_args(ConvArgs *a, const float *x, const aq3d_conv2d_geom *g, con
     a->Ho = g->Ho; a->Wo = g->Wo; a->in_ld = g->in_ld; a->out_ld = g->out_ld; a->out_coff = g->out_coff;
     a->deconv = g->deconv; a->relu = g->relu;
     a->s = a->rinv = a->scal = a->out_mul = nullptr;
+    a->pieces_out = nullptr;
+    a->pieces_ld = 0;
     a->w = nullptr;
     a->rows_total = g->Cout;
     return AQ3D_OK;
 }
 
 extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_conv2d_geom *g, const float *bias,
-                              const float *post_scale, const float *post_shift, float *y, void *stream_) {
+                              const float *post_scale, const float *post_shift, float *y, float *pieces_out,
+                              int32_t pieces_ld, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ConvArgs a;
     int rc = fill_args(&a, x, g, bias, post_scale, post_shift, y, "aq3d_conv2d_i8");
     if (rc != AQ3D_OK) return rc;
+    AQ3D_REQUIRE(!pieces_out || (pieces_ld >= g->out_coff + g->Cout && g->Ho >= 3 && g->Wo >= 3), "aq3d_conv2d_i8: bad pieces_out layout");
+    a.pieces_out = pieces_out;
+    a.pieces_ld = pieces_ld;
     AQ3D_REQUIRE(params, "aq3d_conv2d_i8: null params");
     AQ3D_REQUIRE((g->Cin & 63) == 0, "aq3d_conv2d_i8: Cin=%d must be a multiple of 64", g->Cin);
     AQ3D_REQUIRE((g->Cout & 3) == 0 && (g->out_ld & 3) == 0 && (g->out_coff & 3) == 0, "aq3d_conv2d_i8: Cout/out_ld/out_coff must be multiples of 4");
@@ -399,11 +437,15 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
 }
 
 extern "C" int aq3d_conv2d_f32(const float *x, const float *weight, const aq3d_conv2d_geom *g, const float *bias,
-                               const float *post_scale, const float *post_shift, float *y, void *stream_) {
+                               const float *post_scale, const float *post_shift, float *y, float *pieces_out,
+                               int32_t pieces_ld, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ConvArgs a;
     int rc = fill_args(&a, x, g, bias, post_scale, post_shift, y, "aq3d_conv2d_f32");
     if (rc != AQ3D_OK) return rc;
+    AQ3D_REQUIRE(!pieces_out || pieces_ld >= g->out_coff + g->Cout, "aq3d_conv2d_f32: bad pieces_out layout");
+    a.pieces_out = pieces_out;
+    a.pieces_ld = pieces_ld;
     AQ3D_REQUIRE(weight, "aq3d_conv2d_f32: null weight");
     AQ3D_REQUIRE((g->Cin & 15) == 0, "aq3d_conv2d_f32: Cin=%d must be a multiple of 16", g->Cin);
     a.w = weight;

@@ -36,7 +36,8 @@ typedef int i32x4v __attribute__((ext_vector_type(4)));
 // neighbour or an offset beyond kvol is an out-of-range offset, which the hardware answers with zeros without touching
 // memory — no branches, no dummy traffic, straight-line code with counted vmcnt waits.
 template <int CIN, int COUT, int WR, int WC, int G, int NSUB>
-__global__ __launch_bounds__(256) void spconv_split_kernel(SpconvSplitArgs a) {
+__global__ __launch_bounds__(64 * WR * WC) void spconv_split_kernel(SpconvSplitArgs a) {
+    constexpr int NTH = 64 * WR * WC;                   // threads per workgroup
     constexpr int TM = 16 * WR;
     constexpr int TMS = TM * NSUB;
     constexpr int NT = COUT / (16 * WC);
@@ -45,9 +46,9 @@ __global__ __launch_bounds__(256) void spconv_split_kernel(SpconvSplitArgs a) {
     constexpr int C8 = CIN / 8;                        // 16-byte chunks per (row, offset, half)
     constexpr int AITEMS = TM * G * C8 * 2;            // hi and lo chunks of one sub-tile
     constexpr int WITEMS = COUT * G * C8;
-    constexpr int NA = (AITEMS + 255) / 256;
-    constexpr int NW = (WITEMS + 255) / 256;
-    static_assert(WR * WC == 4, "4 waves");
+    constexpr int NA = (AITEMS + NTH - 1) / NTH;
+    constexpr int NW = (WITEMS + NTH - 1) / NTH;
+    static_assert(WR * WC == 4 || WR * WC == 8, "4 or 8 waves");
     static_assert(CIN % 16 == 0 && COUT % (16 * WC) == 0, "channel granularity");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void spconv_split_kernel(SpconvSplitArgs a) {
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * TMS;
         __syncthreads();
-        for (int t = tid; t < TMS * kvol; t += 256) {
+        for (int t = tid; t < TMS * kvol; t += NTH) {
             int r = row0 + t / kvol;
             nbr_s[t] = (r < n) ? a.nbr[(size_t)row0 * kvol + t] : -1;
         }
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void spconv_split_kernel(SpconvSplitArgs a) {
                 acc_lo[u][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         __syncthreads();
-        for (int r = tid; r < TMS; r += 256) {
+        for (int r = tid; r < TMS; r += NTH) {
             int bits = 0;
             for (int k = 0; k < kvol; ++k)
                 if (nbr_s[r * kvol + k] >= 0) bits |= 1 << (k / G);
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void spconv_split_kernel(SpconvSplitArgs a) {
             const int k0 = p * G, gn = min(G, kvol - k0);
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int t = (AITEMS % 256 == 0) ? tid + 256 * i : min(tid + 256 * i, AITEMS - 1);
+                const int t = (AITEMS % NTH == 0) ? tid + NTH * i : min(tid + NTH * i, AITEMS - 1);
                 const int c8 = t % C8, h = (t / C8) & 1, j = (t / (2 * C8)) % G, r = t / (2 * C8 * G);
                 const int src = nbr_s[(u * TM + r) * kvol + k0 + min(j, gn - 1)];
                 const unsigned off = (src >= 0 && j < gn) ? (unsigned)((src * 2 * CIN + h * CIN + c8 * 8) * 2) : SPLIT_OOB;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void spconv_split_kernel(SpconvSplitArgs a) {
             const int k0 = p * G, gn = min(G, kvol - k0);
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                const int t = (WITEMS % 256 == 0) ? tid + 256 * i : min(tid + 256 * i, WITEMS - 1);
+                const int t = (WITEMS % NTH == 0) ? tid + NTH * i : min(tid + NTH * i, WITEMS - 1);
                 const int c8 = t % C8, j = (t / C8) % G, o = t / (C8 * G);
                 const unsigned off = (j < gn) ? (unsigned)((((k0 + j) * COUT + o) * CIN + c8 * 8) * 2) : SPLIT_OOB;
                 wq[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0);
@@ -130,8 +131,8 @@ __global__ __launch_bounds__(256) void spconv_split_kernel(SpconvSplitArgs a) {
         auto storeA = [&]() {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int t = tid + 256 * i;
-                if (AITEMS % 256 == 0 || t < AITEMS) {
+                const int t = tid + NTH * i;
+                if (AITEMS % NTH == 0 || t < AITEMS) {
                     const int c8 = t % C8, h = (t / C8) & 1, j = (t / (2 * C8)) % G, r = t / (2 * C8 * G);
                     *reinterpret_cast<i32x4v *>(Ahi + h * (TM * LD) + r * LD + j * CIN + c8 * 8) = aq[i];
                 }
@@ -140,8 +141,8 @@ __global__ __launch_bounds__(256) void spconv_split_kernel(SpconvSplitArgs a) {
         auto storeB = [&]() {
 #pragma unroll
             for (int i = 0; i < NW; ++i) {
-                const int t = tid + 256 * i;
-                if (WITEMS % 256 == 0 || t < WITEMS) {
+                const int t = tid + NTH * i;
+                if (WITEMS % NTH == 0 || t < WITEMS) {
                     const int c8 = t % C8, j = (t / C8) % G, o = t / (C8 * G);
                     *reinterpret_cast<i32x4v *>(Bs + o * LD + j * CIN + c8 * 8) = wq[i];
                 }
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256) void spconv_split_kernel(SpconvSplitArgs a) {
         };
         if constexpr (KP > G * CIN) {
             constexpr int PADC = KP - G * CIN;
-            for (int t = tid; t < (2 * TM + COUT) * PADC; t += 256) {
+            for (int t = tid; t < (2 * TM + COUT) * PADC; t += NTH) {
                 const int r = t / PADC, c = G * CIN + t % PADC;
                 Ahi[r * LD + c] = (_Float16)0.f;     // Ahi, Alo and Bs are contiguous with the same row pitch
             }
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(256) void spconv_split_kernel(SpconvSplitArgs a) {
                 if (g == 0) red[wr * COUT + (wc * NT + nt) * 16 + l15] = mx;
             }
             __syncthreads();
-            for (int o = tid; o < COUT; o += 256) {
+            for (int o = tid; o < COUT; o += NTH) {
                 float mx = red[o];
 #pragma unroll
                 for (int w = 1; w < WR; ++w) mx = fmaxf(mx, red[w * COUT + o]);
@@ -270,7 +271,7 @@ static int launch_split(const SpconvSplitArgs &a, hipStream_t stream) {
     const int grid = tiles < 4096 ? (tiles < 1 ? 1 : tiles) : 4096;
     auto kern = spconv_split_kernel<CIN, COUT, WR, WC, G, NSUB>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * WR * WC), lds, stream, a);
     AQ3D_CHECK_LAUNCH("aq3d_spconv(f16 split)");
     return AQ3D_OK;
 }
@@ -298,6 +299,12 @@ int aq3d_spconv_split_dispatch(const void *feats_split, unsigned feats_bytes, co
     AQ3D_SPLIT_CASE(16, 32, 2, 2, 9, 1)
     AQ3D_SPLIT_CASE(32, 32, 2, 2, 4, 1)
     AQ3D_SPLIT_CASE(32, 64, 2, 2, 4, 1)
+    static const bool wide = getenv("AQ3D_SPCONV_WIDE") != nullptr && atoi(getenv("AQ3D_SPCONV_WIDE")) != 0;   // measured: no gain
+    if (wide) {   // 8-wave workgroups (64 rows): same registers per wave, half the weight re-streaming per output row
+        AQ3D_SPLIT_CASE(64, 64, 4, 2, 2, 1)
+        AQ3D_SPLIT_CASE(64, 128, 4, 2, 2, 1)
+        AQ3D_SPLIT_CASE(128, 128, 4, 2, 1, 1)
+    }
     AQ3D_SPLIT_CASE(64, 64, 2, 2, 2, 1)
     AQ3D_SPLIT_CASE(64, 128, 2, 2, 2, 1)
     AQ3D_SPLIT_CASE(128, 128, 2, 2, 1, 1)

@@ -267,6 +267,9 @@ class Engine:
         self.steps.append(("scatter_dense", None))
         self.dense_convs = []
         self._pieces = {}
+        self._producers = {}
+        import os
+        self.fuse_pieces = os.environ.get("AQ3D_FUSE_PIECES", "0") != "0"   # measured slower than the standalone pass (epilogue atomics)
 
         def compile_conv2d(mod, path, x, xH, xW, x_ld, pad_extra, bn, relu, out=None, out_ld=None, out_coff=0):
             """mod: nn.Conv2d | SQConv2d | QuantConv2d | nn.ConvTranspose2d. x: [B, xH, xW, x_ld] buffer."""
@@ -305,6 +308,13 @@ class Engine:
                     rec["pieces_owner"] = pkey not in self._pieces
                     if rec["pieces_owner"]:
                         self._pieces[pkey] = self.arena.alloc(16 * cin)
+                        # if the tensor is written by conv kernels, they produce its piece maxima in their epilogues
+                        prods = self._producers.get(x.data_ptr(), [])
+                        covered = sum(p_["geom"].Cout for p_ in prods)
+                        if prods and covered >= cin and x_ld == cin and xH >= 3 and xW >= 3 and self.fuse_pieces:
+                            for p_ in prods:
+                                p_["pieces_out"] = (self._pieces[pkey], cin)
+                            rec["pieces_owner"] = False
                     rec["pieces"] = self._pieces[pkey]
                     rec["params"] = torch.empty((ops.sq_param_bytes(cin, g.Cout, k),), dtype=torch.uint8, device=dev)
                     rec["amax_x_acc"] = self.arena.alloc(1)
@@ -346,6 +356,8 @@ class Engine:
                 out = torch.zeros((B, Ho, Wo, out_ld or g.Cout), dtype=f32, device=dev)
             rec["out"] = out
             rec["out_hw"] = (Ho, Wo)
+            rec["pieces_out"] = None
+            self._producers.setdefault(out.data_ptr(), []).append(rec)
             self.dense_convs.append(rec)
             self.steps.append(("conv2d", rec))
             return out, Ho, Wo
@@ -537,6 +549,9 @@ class Engine:
     def _run_conv2d(self, rec, B):
         g = rec["geom"]
         x, out = rec["x"], rec["out"]
+        po = None
+        if rec["pieces_out"] is not None:
+            po = self.arena.view(rec["pieces_out"][0], (16, rec["pieces_out"][1]))
         if rec["kind"] == "i8":
             pieces = self.arena.view(rec["pieces"], (16, g.Cin))
             if rec["pieces_owner"]:
@@ -548,14 +563,16 @@ class Engine:
                             rec["a_bits"], rec["static_x"], rec["static_w"], self.arena.view(rec["amax_x_acc"]))
             with _Timed(self, "conv2d_i8"):
                 for b in range(B):
-                    ops.conv2d_i8(x[b], rec["params"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b])
+                    ops.conv2d_i8(x[b], rec["params"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b],
+                                  pieces_out=po)
         else:
             cal = rec.get("calib")
             if cal is not None:
                 self._harvest_calib(rec, cal, B)
             with _Timed(self, "conv2d_f32"):
                 for b in range(B):
-                    ops.conv2d_f32(x[b], rec["weight"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b])
+                    ops.conv2d_f32(x[b], rec["weight"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b],
+                                   pieces_out=po)
 
     def _harvest_calib(self, rec, cal, B):
         """Calibration forward of an SQConv2d/QuantConv2d: the amax its two quantizers would see this batch."""
@@ -599,6 +616,13 @@ class Engine:
         B = bev_nhwc.shape[0]
         self.arena.clear()
         self.bev_cat[:B].copy_(bev_nhwc)
+        # the piece maxima of bev_cat normally come out of the deblock epilogues, which do not run here
+        for kind, rec in self.steps[self.head_first_step:]:
+            if kind == "conv2d" and rec["kind"] == "i8" and rec["x"] is self.bev_cat and not rec["pieces_owner"]:
+                g = rec["geom"]
+                for b in range(B):
+                    ops.piece_absmax(self.bev_cat[b], g.H, g.W, g.Cin, g.in_ld, self.arena.view(rec["pieces"], (16, g.Cin)))
+                break
         self._run_steps(self.steps[self.head_first_step:], B)
         return B
 

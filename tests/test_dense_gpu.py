@@ -69,8 +69,12 @@ def test_conv2d_i8_vs_sqconv2d(dev, Cin, Cout, H, W, stride, alpha, use_bias, us
     wcol = wk.abs().max(dim=0)[0].contiguous()
     pieces = ops.piece_absmax(xg, H, W, Cin)
     params = ops.sq_prep(pieces, wk, wcol, geom, alpha)
+    po = torch.zeros((16, Cout), device=dev)
     y = ops.conv2d_i8(xg, params, geom, bias=None if bias is None else bias.to(dev),
-                      post_scale=None if ps is None else ps.to(dev), post_shift=None if pt is None else pt.to(dev))
+                      post_scale=None if ps is None else ps.to(dev), post_shift=None if pt is None else pt.to(dev),
+                      pieces_out=po)
+    # fused piece maxima of the output == the standalone pass over the output
+    np.testing.assert_array_equal(po.cpu().numpy(), ops.piece_absmax(y, geom.Ho, geom.Wo, Cout).cpu().numpy())
     y = y.cpu().permute(2, 0, 1)[None]
     amax_x = ops.sq_param_views(params, Cin, Cout, 3)["scal"][1].item()
     assert amax_x == pytest.approx(float(st["amax_x"]), rel=1e-6)
@@ -120,7 +124,10 @@ def test_deconv_f32(dev, Cin, Cout, H, W, d):
     ref = torch.relu(F.conv_transpose2d(x, w, None, stride=d) * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))
     geom = ops.conv_geom(H, W, Cin, Cout, 1, 1, 0, out_ld=2 * Cout, out_coff=Cout, deconv=d, relu=True)
     buf = torch.zeros((H * d, W * d, 2 * Cout), device=dev)
-    ops.conv2d_f32(_nhwc(x).to(dev), ops.deconv_weight_to_k(w).to(dev), geom, None, ps.to(dev), pt.to(dev), out=buf)
+    po = torch.zeros((16, 2 * Cout), device=dev)
+    ops.conv2d_f32(_nhwc(x).to(dev), ops.deconv_weight_to_k(w).to(dev), geom, None, ps.to(dev), pt.to(dev), out=buf, pieces_out=po)
+    if H * d >= 3 and W * d >= 3:
+        np.testing.assert_array_equal(po.cpu().numpy(), ops.piece_absmax(buf, H * d, W * d, 2 * Cout).cpu().numpy())
     y = buf.cpu()[..., Cout:].permute(2, 0, 1)[None]
     assert float((y - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
