@@ -30,6 +30,8 @@
  *                            pcdet/models/dense_heads/center_head.py:22-29,75-82 (the layers left in fp32)
  *   aq3d_center_decode       centernet_utils.decode_bbox_from_heatmap, model_utils/centernet_utils.py:155-241
  *   aq3d_nms_rotated         iou3d_nms_utils.nms_gpu → iou3d_nms.cpp:137-183 + iou3d_nms_kernel.cu:295-339
+ *   aq3d_bev_merge           VoxelResBackBone8xVoxelNeXt.bev_out, spconv_backbone_voxelnext.py:149-198
+ *   aq3d_voxel_decode        centernet_utils.decode_bbox_from_voxels_nuscenes, model_utils/centernet_utils.py:243-354
  *   aq3d_boxes_iou3d / aq3d_recall_counts
  *                            iou3d_nms_utils.boxes_iou3d_gpu (iou3d_nms_utils.py:48-81, kernel iou3d_nms_kernel.cu:236-249) and
  *                            the recall bookkeeping of Detector3DTemplate.generate_recall_record (detector3d_template.py:286-328)
@@ -265,6 +267,32 @@ int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_t *count, i
 int aq3d_gather_dets(const float *boxes, int32_t box_ld, const float *scores, const int32_t *labels,
                      const int32_t *class_map, const int32_t *keep, const int32_t *keep_count, int32_t cap,
                      float *boxes_out, float *scores_out, int64_t *labels_out, void *stream);
+
+/* ---------------------------------------------------------------- VoxelNeXt (fully sparse) extras ---------------- */
+
+size_t aq3d_bev_merge_workspace_bytes(int32_t n_levels, int32_t cap_in, int32_t out_table_size);
+
+/* VoxelResBackBone8xVoxelNeXt.bev_out (pcdet/models/backbones_3d/spconv_backbone_voxelnext.py:149-198): union of up to 3
+ * index levels projected onto the (y, x) plane — level l coordinates multiplied by scales[l] — with the features of
+ * coinciding sites summed (fixed (level, z) order, no float atomics).
+ *   coords/counts/feats/keys/vals/table_sizes: per level, host arrays of n_levels device pointers / sizes; every level has
+ *   capacity cap_in, C channels and a valid 3-D hash table (aq3d_hash_build / aq3d_conv_outputs); shapes = [n_levels][3] (z,y,x).
+ *   Output: coords_out i32 [cap_out,4] rows (b, 0, y, x) in first-candidate order, count_out, feats_out f32 [cap_out, C] and
+ *   the 2-D hash table of the merged set (shape (1, H, W)) in out_keys / out_vals. */
+int aq3d_bev_merge(const int32_t *const *coords, const int32_t *const *counts, const float *const *feats,
+                   const int64_t *const *keys, const int32_t *const *vals, const int32_t *table_sizes,
+                   const int32_t *shapes, const int32_t *scales, int32_t n_levels, int32_t cap_in, int32_t C,
+                   int32_t H, int32_t W, int32_t *coords_out, int32_t *count_out, float *feats_out, int32_t cap_out,
+                   int64_t *out_keys, int32_t *out_vals, int32_t out_table_size, void *workspace, size_t workspace_bytes,
+                   void *stream);
+
+/* centernet_utils.decode_bbox_from_voxels_nuscenes (model_utils/centernet_utils.py:243-354) for ONE sample: like
+ * aq3d_center_decode, but the candidates are the *count live rows of a sparse head output (row-major maps with pixel
+ * strides cfg->hm_ld / cfg->reg_ld) and their grid position comes from coords rows (b, z, y, x). cfg->H / W are ignored. */
+int aq3d_voxel_decode(const float *hm, const float *center, const float *center_z, const float *dim, const float *rot,
+                      const float *vel, const int32_t *coords, const int32_t *count, int32_t cap, const aq3d_decode_cfg *cfg,
+                      float *boxes_out, float *scores_out, int32_t *labels_out, int32_t *count_out, void *workspace,
+                      size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------- evaluation helpers (recall vs ground truth) ---- */
 

@@ -61,8 +61,11 @@ __device__ __forceinline__ float sigmoidf_dev(float x) { return __fdiv_rn(1.0f, 
 // ------------------------------------------------------------------ stage 1: per-class top-K (radix select + sort)
 // grid = num_classes, block = 1024. Writes K composite keys (score bits << 32 | ~index) per class, sorted descending;
 // slots beyond the number of pixels hold 0.
-__global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__restrict__ hm, int hm_ld, int L, int K,
-                                                              int Kpad, int cache_keys, u64 *__restrict__ out) {
+__global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__restrict__ hm, int hm_ld, int L_static,
+                                                              const int *__restrict__ count, int K, int Kpad,
+                                                              int cache_keys, u64 *__restrict__ out) {
+    int L = L_static;            // dense map: H*W pixels; sparse head: the live rows (device count, capped by L_static)
+    if (count) { L = *count; if (L > L_static) L = L_static; if (L < 0) L = 0; }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *sel = reinterpret_cast<u64 *>(smem_raw);          // [Kpad]
     int *hist = reinterpret_cast<int *>(sel + Kpad);       // [256]
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
 struct DecodeParams {
     aq3d_decode_cfg c;
     const float *center, *center_z, *dim, *rot, *vel;
+    const int *coords;      // sparse head: rows (b, z|0, y, x) of the voxels; NULL for a dense map
 };
 
 __global__ __launch_bounds__(1024) void decode_kernel(const u64 *__restrict__ cand, int ncand, int Npad, DecodeParams q,
@@ -222,7 +226,9 @@ __global__ __launch_bounds__(1024) void decode_kernel(const u64 *__restrict__ ca
         label = pos / K;
         const int pix = (int)(0xffffffffu - (unsigned int)(cand[pos] & 0xffffffffull));
         score = __uint_as_float((unsigned int)(kv >> 32));
-        const int yi = pix / q.c.W, xi = pix - yi * q.c.W;
+        int yi, xi;
+        if (q.coords) { yi = q.coords[(size_t)pix * 4 + 2]; xi = q.coords[(size_t)pix * 4 + 3]; }
+        else { yi = pix / q.c.W; xi = pix - yi * q.c.W; }
         const size_t ro = (size_t)pix * q.c.reg_ld;
         const float cx = q.center[ro + 0], cy = q.center[ro + 1];
         float xs = __fadd_rn((float)xi, cx), ys = __fadd_rn((float)yi, cy);
@@ -282,16 +288,51 @@ extern "C" int aq3d_center_decode(const float *hm, const float *center, const fl
     if (cache_keys) lds1 += (size_t)L * 4;
     if (lds1 > 64 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(topk_per_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipLaunchKernelGGL(topk_per_class_kernel, dim3(cfg->num_classes), dim3(1024), lds1, stream, hm, cfg->hm_ld, L, K, Kpad, cache_keys, cand);
+    hipLaunchKernelGGL(topk_per_class_kernel, dim3(cfg->num_classes), dim3(1024), lds1, stream, hm, cfg->hm_ld, L, (const int *)nullptr,
+                       K, Kpad, cache_keys, cand);
     const int ncand = cfg->num_classes * K;
     const int Npad = next_pow2(ncand);
     DecodeParams q;
-    q.c = *cfg; q.center = center; q.center_z = center_z; q.dim = dim; q.rot = rot; q.vel = vel;
+    q.c = *cfg; q.center = center; q.center_z = center_z; q.dim = dim; q.rot = rot; q.vel = vel; q.coords = nullptr;
     size_t lds2 = (size_t)Npad * 8;
     if (lds2 > 64 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
     hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(1024), lds2, stream, cand, ncand, Npad, q, boxes_out, scores_out, labels_out, count_out);
     AQ3D_CHECK_LAUNCH("aq3d_center_decode");
+    return AQ3D_OK;
+}
+
+extern "C" int aq3d_voxel_decode(const float *hm, const float *center, const float *center_z, const float *dim,
+                                 const float *rot, const float *vel, const int32_t *coords, const int32_t *count, int32_t cap,
+                                 const aq3d_decode_cfg *cfg, float *boxes_out, float *scores_out, int32_t *labels_out,
+                                 int32_t *count_out, void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(hm && center && center_z && dim && rot && coords && count && cfg && boxes_out && scores_out && labels_out &&
+                     count_out && workspace, "aq3d_voxel_decode: null argument");
+    AQ3D_REQUIRE(!cfg->has_vel || vel, "aq3d_voxel_decode: has_vel without vel rows");
+    AQ3D_REQUIRE(cfg->num_classes >= 1 && cfg->num_classes <= 16 && cfg->K >= 1 && cfg->K <= 512 && cap >= 1,
+                 "aq3d_voxel_decode: num_classes=%d K=%d cap=%d", cfg->num_classes, cfg->K, cap);
+    if (workspace_bytes < aq3d_center_decode_workspace_bytes(cfg)) {
+        aq3d_set_error("aq3d_voxel_decode: workspace too small");
+        return AQ3D_ERR_WORKSPACE;
+    }
+    const int K = cfg->K, Kpad = next_pow2(K);
+    u64 *cand = (u64 *)workspace;
+    size_t lds1 = (size_t)Kpad * 8 + 256 * 4 + 16 * 4;
+    const int cache_keys = (lds1 + (size_t)cap * 4 <= 150 * 1024) ? 1 : 0;
+    if (cache_keys) lds1 += (size_t)cap * 4;
+    if (lds1 > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(topk_per_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    hipLaunchKernelGGL(topk_per_class_kernel, dim3(cfg->num_classes), dim3(1024), lds1, stream, hm, cfg->hm_ld, cap, count, K, Kpad,
+                       cache_keys, cand);
+    const int ncand = cfg->num_classes * K, Npad = next_pow2(ncand);
+    DecodeParams q;
+    q.c = *cfg; q.center = center; q.center_z = center_z; q.dim = dim; q.rot = rot; q.vel = vel; q.coords = coords;
+    size_t lds2 = (size_t)Npad * 8;
+    if (lds2 > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(1024), lds2, stream, cand, ncand, Npad, q, boxes_out, scores_out, labels_out, count_out);
+    AQ3D_CHECK_LAUNCH("aq3d_voxel_decode");
     return AQ3D_OK;
 }
 

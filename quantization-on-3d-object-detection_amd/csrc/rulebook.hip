@@ -243,3 +243,148 @@ extern "C" int aq3d_conv_outputs(const int32_t *coords_in, const int32_t *count_
     AQ3D_CHECK_LAUNCH("aq3d_conv_outputs");
     return AQ3D_OK;
 }
+
+// ---------------- VoxelNeXt bev_out: union of up to 3 index levels projected to 2-D, features summed per site ----------
+// Reference: VoxelResBackBone8xVoxelNeXt.forward + bev_out (pcdet/models/backbones_3d/spconv_backbone_voxelnext.py:149-198):
+//   x5.indices[:, 1:] *= 2; x6.indices[:, 1:] *= 4; cat(x4, x5, x6); drop z; torch.unique(dim=0) + index_add_.
+// Here: candidates (level, row) are inserted into a 2-D hash, the first candidate of a site names its output row
+// (deterministic order, no sort), and every output row then GATHERS its contributions through the levels' 3-D hash tables in
+// a fixed (level, z) order — no float atomics, bit-reproducible sums.
+struct MergeLevels {
+    const int *coords[3];
+    const int *count[3];
+    const float *feats[3];
+    const int64_t *keys[3];
+    const int *vals[3];
+    int table_size[3];
+    int sz[3], sy[3], sx[3];   // 3-D shapes of the levels
+    int scale[3];
+    int n_levels, cap_in, C;
+};
+
+__global__ __launch_bounds__(RB_BLOCK) void merge_candidates_kernel(MergeLevels L, int H, int W, int64_t *out_keys,
+                                                                   int out_table_size, int *first, int *cslot) {
+    const long long total = (long long)L.n_levels * L.cap_in;
+    for (long long t = (long long)blockIdx.x * RB_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * RB_BLOCK) {
+        const int l = (int)(t / L.cap_in), m = (int)(t - (long long)l * L.cap_in);
+        int n = *L.count[l];
+        if (n > L.cap_in) n = L.cap_in;
+        int slot = -1;
+        if (m < n) {
+            const int4 c = reinterpret_cast<const int4 *>(L.coords[l])[m];
+            const int y = c.z * L.scale[l], x = c.w * L.scale[l];
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                slot = aq3d_hash_insert(out_keys, out_table_size, coord_key(c.x, 0, y, x, 1, H, W));
+                if (slot >= 0) atomicMin(&first[slot], (int)t);
+            }
+        }
+        cslot[t] = slot;
+    }
+}
+
+__global__ __launch_bounds__(RB_BLOCK) void merge_flags_kernel(long long total, const int *first, const int *cslot, int *flags,
+                                                              int *n_dev) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_dev = (int)total;   // scan length as a device scalar
+    for (long long t = (long long)blockIdx.x * RB_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * RB_BLOCK) {
+        const int s = cslot[t];
+        flags[t] = (s >= 0 && first[s] == (int)t) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(RB_BLOCK) void merge_emit_kernel(long long total, int H, int W, const int64_t *out_keys, int *out_vals,
+                                                             const int *flags, const int *prefix, const int *cslot,
+                                                             const int *total_out, int *coords_out, int cap_out, int *count_out) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = *total_out < cap_out ? *total_out : cap_out;
+    for (long long t = (long long)blockIdx.x * RB_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * RB_BLOCK) {
+        if (!flags[t]) continue;
+        const int row = prefix[t], s = cslot[t];
+        if (row >= cap_out) { out_vals[s] = -1; continue; }
+        out_vals[s] = row;
+        int64_t key = out_keys[s];
+        const int x = (int)(key % W); key /= W;
+        const int y = (int)(key % H); key /= H;
+        reinterpret_cast<int4 *>(coords_out)[row] = make_int4((int)key, 0, y, x);
+    }
+}
+
+// thread = (output row, 4 channels): sum of the contributing rows in (level, z) order
+__global__ __launch_bounds__(RB_BLOCK) void merge_sum_kernel(MergeLevels L, const int *coords_out, const int *count_out, int cap_out,
+                                                            float *feats_out) {
+    int n = *count_out;
+    if (n > cap_out) n = cap_out;
+    const int c4n = L.C >> 2;
+    const long long total = (long long)n * c4n;
+    for (long long t = (long long)blockIdx.x * RB_BLOCK + threadIdx.x; t < total; t += (long long)gridDim.x * RB_BLOCK) {
+        const int row = (int)(t / c4n), c4 = (int)(t - (long long)row * c4n);
+        const int4 c = reinterpret_cast<const int4 *>(coords_out)[row];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int l = 0; l < L.n_levels; ++l) {
+            const int sc = L.scale[l];
+            if (c.z % sc != 0 || c.w % sc != 0) continue;
+            const int y = c.z / sc, x = c.w / sc;
+            if (y >= L.sy[l] || x >= L.sx[l]) continue;
+            for (int z = 0; z < L.sz[l]; ++z) {
+                const int slot = aq3d_hash_find(L.keys[l], L.table_size[l], coord_key(c.x, z, y, x, L.sz[l], L.sy[l], L.sx[l]));
+                if (slot < 0) continue;
+                const float4 v = *reinterpret_cast<const float4 *>(L.feats[l] + (size_t)L.vals[l][slot] * L.C + c4 * 4);
+                acc.x = __fadd_rn(acc.x, v.x); acc.y = __fadd_rn(acc.y, v.y);
+                acc.z = __fadd_rn(acc.z, v.z); acc.w = __fadd_rn(acc.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4 *>(feats_out + (size_t)row * L.C + c4 * 4) = acc;
+    }
+}
+
+extern "C" size_t aq3d_bev_merge_workspace_bytes(int32_t n_levels, int32_t cap_in, int32_t out_table_size) {
+    const size_t nc = (size_t)n_levels * cap_in;
+    return rb_align((size_t)out_table_size * 4) + 3 * rb_align(nc * 4) + rb_align((size_t)aq3d_scan_chunks_for((int)nc) * 4 + 4) + 512;
+}
+
+extern "C" int aq3d_bev_merge(const int32_t *const *coords, const int32_t *const *counts, const float *const *feats,
+                              const int64_t *const *keys, const int32_t *const *vals, const int32_t *table_sizes,
+                              const int32_t *shapes /* [n_levels][3] */, const int32_t *scales, int32_t n_levels, int32_t cap_in,
+                              int32_t C, int32_t H, int32_t W, int32_t *coords_out, int32_t *count_out, float *feats_out,
+                              int32_t cap_out, int64_t *out_keys, int32_t *out_vals, int32_t out_table_size, void *workspace,
+                              size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(coords && counts && feats && keys && vals && table_sizes && shapes && scales && coords_out && count_out &&
+                     feats_out && out_keys && out_vals && workspace, "aq3d_bev_merge: null argument");
+    AQ3D_REQUIRE(n_levels >= 1 && n_levels <= 3 && cap_in > 0 && cap_out > 0 && C >= 4 && (C & 3) == 0 && H > 0 && W > 0,
+                 "aq3d_bev_merge: bad sizes");
+    AQ3D_REQUIRE(aq3d_is_pow2(out_table_size) && out_table_size >= 2 * cap_out, "aq3d_bev_merge: out_table_size=%d must be pow2 >= 2*cap_out", out_table_size);
+    if (workspace_bytes < aq3d_bev_merge_workspace_bytes(n_levels, cap_in, out_table_size)) {
+        aq3d_set_error("aq3d_bev_merge: workspace too small");
+        return AQ3D_ERR_WORKSPACE;
+    }
+    MergeLevels L;
+    for (int l = 0; l < 3; ++l) {
+        const int k = l < n_levels ? l : 0;
+        L.coords[l] = coords[k]; L.count[l] = counts[k]; L.feats[l] = feats[k]; L.keys[l] = keys[k]; L.vals[l] = vals[k];
+        L.table_size[l] = table_sizes[k]; L.sz[l] = shapes[3 * k]; L.sy[l] = shapes[3 * k + 1]; L.sx[l] = shapes[3 * k + 2];
+        L.scale[l] = scales[k];
+        AQ3D_REQUIRE(L.scale[l] >= 1, "aq3d_bev_merge: scale must be >= 1");
+    }
+    L.n_levels = n_levels; L.cap_in = cap_in; L.C = C;
+    const size_t nc = (size_t)n_levels * cap_in;
+    char *p = (char *)workspace;
+    int *first = (int *)p;  p += rb_align((size_t)out_table_size * 4);
+    int *cslot = (int *)p;  p += rb_align(nc * 4);
+    int *flags = (int *)p;  p += rb_align(nc * 4);
+    int *prefix = (int *)p; p += rb_align(nc * 4);
+    int *chunk_sums = (int *)p; p += rb_align((size_t)aq3d_scan_chunks_for((int)nc) * 4 + 4);
+    int *total = (int *)p;
+    int *n_dev = total + 1;
+    hipMemsetAsync(out_keys, 0xff, (size_t)out_table_size * 8, stream);
+    hipMemsetAsync(first, 0x7f, (size_t)out_table_size * 4, stream);
+    const int grid = aq3d_grid((int64_t)nc, RB_BLOCK, 4096);
+    hipLaunchKernelGGL(merge_candidates_kernel, dim3(grid), dim3(RB_BLOCK), 0, stream, L, H, W, out_keys, out_table_size, first, cslot);
+    hipLaunchKernelGGL(merge_flags_kernel, dim3(grid), dim3(RB_BLOCK), 0, stream, (long long)nc, first, cslot, flags, n_dev);
+    int rc = aq3d_scan_flags(flags, n_dev, 1, (int)nc, prefix, total, chunk_sums, stream);
+    if (rc != AQ3D_OK) return rc;
+    hipLaunchKernelGGL(merge_emit_kernel, dim3(grid), dim3(RB_BLOCK), 0, stream, (long long)nc, H, W, out_keys, out_vals, flags, prefix,
+                       cslot, total, coords_out, cap_out, count_out);
+    hipLaunchKernelGGL(merge_sum_kernel, dim3(aq3d_grid((int64_t)cap_out * (C / 4), RB_BLOCK, 4096)), dim3(RB_BLOCK), 0, stream, L,
+                       coords_out, count_out, cap_out, feats_out);
+    AQ3D_CHECK_LAUNCH("aq3d_bev_merge");
+    return AQ3D_OK;
+}

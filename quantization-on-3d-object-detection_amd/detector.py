@@ -18,10 +18,10 @@ from .engine import Engine
 from .quant import surgery_epoch
 
 VFE = {"MeanVFE": M.MeanVFE}
-BACKBONE_3D = {"VoxelResBackBone8x": M.VoxelResBackBone8x}
+BACKBONE_3D = {"VoxelResBackBone8x": M.VoxelResBackBone8x, "VoxelResBackBone8xVoxelNeXt": M.VoxelResBackBone8xVoxelNeXt}
 MAP_TO_BEV = {"HeightCompression": M.HeightCompression}
 BACKBONE_2D = {"BaseBEVBackbone": M.BaseBEVBackbone}
-DENSE_HEAD = {"CenterHead": M.CenterHead}
+DENSE_HEAD = {"CenterHead": M.CenterHead, "VoxelNeXtHead": M.VoxelNeXtHead}
 
 
 class Detector3DTemplate(nn.Module):
@@ -110,7 +110,9 @@ class Detector3DTemplate(nn.Module):
         if self.model_cfg.get("DENSE_HEAD", None) is None:
             return None, model_info_dict
         m = DENSE_HEAD[self.model_cfg.DENSE_HEAD.NAME](
-            model_cfg=self.model_cfg.DENSE_HEAD, input_channels=model_info_dict["num_bev_features"],
+            model_cfg=self.model_cfg.DENSE_HEAD,
+            input_channels=model_info_dict["num_bev_features"] if "num_bev_features" in model_info_dict
+            else self.model_cfg.DENSE_HEAD.INPUT_FEATURES,
             num_class=self.num_class if not self.model_cfg.DENSE_HEAD.CLASS_AGNOSTIC else 1, class_names=self.class_names,
             grid_size=model_info_dict["grid_size"], point_cloud_range=model_info_dict["point_cloud_range"],
             predict_boxes_when_training=self.model_cfg.get("ROI_HEAD", False),
@@ -255,7 +257,12 @@ class CenterPoint(Detector3DTemplate):
         return recall_dict
 
 
-DETECTORS = {"CenterPoint": CenterPoint}
+class VoxelNeXt(CenterPoint):
+    """pcdet/models/detectors/voxelnext.py:3-44 — same forward / post_processing shape as CenterPoint, fully sparse modules
+    (vfe → VoxelResBackBone8xVoxelNeXt → VoxelNeXtHead). One sample per forward in this build."""
+
+
+DETECTORS = {"CenterPoint": CenterPoint, "VoxelNeXt": VoxelNeXt}
 
 
 def build_detector(model_cfg, num_class, dataset):

@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class Aq3dError(RuntimeError):
@@ -65,6 +65,10 @@ SIGNATURES = {
     "aq3d_nms_workspace_bytes": (c_size_t, [c_int32]),
     "aq3d_nms_rotated": (c_int32, [P, c_int32, P, c_int32, c_float, c_int32, P, P, P, c_size_t, P]),
     "aq3d_gather_dets": (c_int32, [P, c_int32, P, P, P, P, P, c_int32, P, P, P, P]),
+    "aq3d_bev_merge_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "aq3d_bev_merge": (c_int32, [P, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, c_int32, P, P,
+                                 c_int32, P, c_size_t, P]),
+    "aq3d_voxel_decode": (c_int32, [P, P, P, P, P, P, P, P, c_int32, POINTER(DecodeCfg), P, P, P, P, P, c_size_t, P]),
     "aq3d_boxes_iou3d": (c_int32, [P, c_int32, c_int32, P, c_int32, c_int32, P, P]),
     "aq3d_recall_counts": (c_int32, [P, c_int32, c_int32, P, c_int32, P, P]),
 }

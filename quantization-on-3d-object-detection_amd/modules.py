@@ -21,6 +21,10 @@ def _triple(v):
     return tuple(v) if isinstance(v, (tuple, list)) else (v, v, v)
 
 
+def _ntuple(v, n):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+
+
 class SparseModule(nn.Module):
     """Marker base class (spconv.pytorch.modules.SparseModule)."""
 
@@ -33,10 +37,11 @@ class SparseConvolution(SparseModule):
     """Sparse conv parameters, KRSC weight layout [Cout, kz, ky, kx, Cin] as spconv 2.x stores it."""
 
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, indice_key=None,
-                 subm=False):
+                 subm=False, ndim=3):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
-        self.kernel_size, self.stride, self.padding = _triple(kernel_size), _triple(stride), _triple(padding)
+        self.ndim = ndim
+        self.kernel_size, self.stride, self.padding = _ntuple(kernel_size, ndim), _ntuple(stride, ndim), _ntuple(padding, ndim)
         self.subm = subm
         self.indice_key = indice_key
         self.weight = nn.Parameter(torch.empty(out_channels, *self.kernel_size, in_channels))
@@ -56,6 +61,18 @@ class SubMConv3d(SparseConvolution):
 class SparseConv3d(SparseConvolution):
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, indice_key=None):
         super().__init__(in_channels, out_channels, kernel_size, stride, padding, bias, indice_key, subm=False)
+
+
+class SubMConv2d(SparseConvolution):
+    """2-D submanifold conv (VoxelNeXt tail / head), weight [Cout, ky, kx, Cin]."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, indice_key=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, bias, indice_key, subm=True, ndim=2)
+
+
+class SparseConv2d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True, indice_key=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, bias, indice_key, subm=False, ndim=2)
 
 
 class SparseSequential(nn.Sequential, SparseModule):
@@ -269,6 +286,110 @@ class CenterHead(nn.Module):
 
     def forward(self, *a, **k):
         raise RuntimeError("CenterHead is a parameter container; run the detector")
+
+
+class VoxelResBackBone8xVoxelNeXt(nn.Module):
+    """pcdet/models/backbones_3d/spconv_backbone_voxelnext.py:69-147 — six 3-D stages, 2-D tail (conv_out, shared_conv)."""
+
+    def __init__(self, model_cfg, input_channels, grid_size, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        ks = model_cfg.get("SPCONV_KERNEL_SIZES", [3, 3, 3, 3])
+        ch = model_cfg.get("CHANNELS", [16, 32, 64, 128, 128])
+        out_channel = model_cfg.get("OUT_CHANNEL", 128)
+        self.sparse_shape = [int(v) for v in (np.asarray(grid_size)[::-1] + np.array([1, 0, 0]))]
+        self.conv_input = SparseSequential(
+            SubMConv3d(input_channels, ch[0], 3, padding=1, bias=False, indice_key="subm1"), norm_fn(ch[0]), nn.ReLU())
+        block = post_act_block
+        sbb = lambda c, key: SparseBasicBlock(c, c, bias=True, norm_fn=norm_fn, indice_key=key)
+        self.conv1 = SparseSequential(sbb(ch[0], "res1"), sbb(ch[0], "res1"))
+        self.conv2 = SparseSequential(
+            block(ch[0], ch[1], ks[0], norm_fn=norm_fn, stride=2, padding=int(ks[0] // 2), indice_key="spconv2", conv_type="spconv"),
+            sbb(ch[1], "res2"), sbb(ch[1], "res2"))
+        self.conv3 = SparseSequential(
+            block(ch[1], ch[2], ks[1], norm_fn=norm_fn, stride=2, padding=int(ks[1] // 2), indice_key="spconv3", conv_type="spconv"),
+            sbb(ch[2], "res3"), sbb(ch[2], "res3"))
+        self.conv4 = SparseSequential(
+            block(ch[2], ch[3], ks[2], norm_fn=norm_fn, stride=2, padding=int(ks[2] // 2), indice_key="spconv4", conv_type="spconv"),
+            sbb(ch[3], "res4"), sbb(ch[3], "res4"))
+        self.conv5 = SparseSequential(
+            block(ch[3], ch[4], ks[3], norm_fn=norm_fn, stride=2, padding=int(ks[3] // 2), indice_key="spconv5", conv_type="spconv"),
+            sbb(ch[4], "res5"), sbb(ch[4], "res5"))
+        self.conv6 = SparseSequential(
+            block(ch[4], ch[4], ks[3], norm_fn=norm_fn, stride=2, padding=int(ks[3] // 2), indice_key="spconv6", conv_type="spconv"),
+            sbb(ch[4], "res6"), sbb(ch[4], "res6"))
+        self.conv_out = SparseSequential(
+            SparseConv2d(ch[3], out_channel, 3, stride=1, padding=1, bias=False, indice_key="spconv_down2"),
+            norm_fn(out_channel), nn.ReLU())
+        self.shared_conv = SparseSequential(
+            SubMConv2d(out_channel, out_channel, 3, stride=1, padding=1, bias=True), nn.BatchNorm1d(out_channel), nn.ReLU(True))
+        self.num_point_features = out_channel
+        self.backbone_channels = {"x_conv1": ch[0], "x_conv2": ch[1], "x_conv3": ch[2], "x_conv4": ch[3]}
+
+    def forward(self, *a, **k):
+        raise RuntimeError("VoxelResBackBone8xVoxelNeXt is a parameter container; run the detector")
+
+
+class SparseSeparateHead(nn.Module):
+    """pcdet/models/dense_heads/voxelnext_head.py:13-47 — per-branch SubMConv2d stacks on the sparse BEV tensor."""
+
+    def __init__(self, input_channels, sep_head_dict, kernel_size, init_bias=-2.19, use_bias=False):
+        super().__init__()
+        self.sep_head_dict = sep_head_dict
+        for cur_name in self.sep_head_dict:
+            output_channels = self.sep_head_dict[cur_name]["out_channels"]
+            num_conv = self.sep_head_dict[cur_name]["num_conv"]
+            fc_list = []
+            for _ in range(num_conv - 1):
+                fc_list.append(SparseSequential(
+                    SubMConv2d(input_channels, input_channels, kernel_size, padding=int(kernel_size // 2), bias=use_bias,
+                               indice_key=cur_name),
+                    nn.BatchNorm1d(input_channels), nn.ReLU()))
+            fc_list.append(SubMConv2d(input_channels, output_channels, 1, bias=True, indice_key=cur_name + "out"))
+            fc = nn.Sequential(*fc_list)
+            if "hm" in cur_name:
+                fc[-1].bias.data.fill_(init_bias)
+            self.__setattr__(cur_name, fc)
+
+    def forward(self, *a, **k):
+        raise RuntimeError("SparseSeparateHead is a parameter container; run the detector")
+
+
+class VoxelNeXtHead(nn.Module):
+    """Inference half of pcdet/models/dense_heads/voxelnext_head.py:50-110,418-559 (no IoU branch / double flip)."""
+
+    def __init__(self, model_cfg, input_channels, num_class, class_names, grid_size, point_cloud_range, voxel_size,
+                 predict_boxes_when_training=False):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.grid_size = grid_size
+        self.point_cloud_range = point_cloud_range
+        self.voxel_size = voxel_size
+        self.feature_map_stride = self.model_cfg.TARGET_ASSIGNER_CONFIG.get("FEATURE_MAP_STRIDE", None)
+        self.class_names = class_names
+        assert not self.model_cfg.get("IOU_BRANCH", False), "IoU branch (Waymo VoxelNeXt) is outside the nuScenes config"
+        assert not self.model_cfg.get("DOUBLE_FLIP", False), "double-flip test-time augmentation is not on the path"
+        self.class_names_each_head, self.class_id_mapping_each_head = [], []
+        for cur_class_names in self.model_cfg.CLASS_NAMES_EACH_HEAD:
+            self.class_names_each_head.append([x for x in cur_class_names if x in class_names])
+            self.class_id_mapping_each_head.append(
+                torch.tensor([self.class_names.index(x) for x in cur_class_names if x in class_names], dtype=torch.int32))
+        assert sum(len(x) for x in self.class_names_each_head) == len(self.class_names)
+        kernel_size_head = self.model_cfg.get("KERNEL_SIZE_HEAD", 3)
+        self.heads_list = nn.ModuleList()
+        self.separate_head_cfg = self.model_cfg.SEPARATE_HEAD_CFG
+        for cur_class_names in self.class_names_each_head:
+            cur_head_dict = {k: dict(v) for k, v in self.separate_head_cfg.HEAD_DICT.items()}
+            cur_head_dict["hm"] = dict(out_channels=len(cur_class_names), num_conv=self.model_cfg.NUM_HM_CONV)
+            self.heads_list.append(SparseSeparateHead(
+                input_channels=self.model_cfg.get("SHARED_CONV_CHANNEL", 128), sep_head_dict=cur_head_dict,
+                kernel_size=kernel_size_head, init_bias=-2.19, use_bias=self.model_cfg.get("USE_BIAS_BEFORE_NORM", False)))
+        self.predict_boxes_when_training = predict_boxes_when_training
+
+    def forward(self, *a, **k):
+        raise RuntimeError("VoxelNeXtHead is a parameter container; run the detector")
 
 
 def find_all_spconv_keys(model, prefix=""):

@@ -91,6 +91,19 @@ class QConvNd(SparseModule):
         self.act_quant = TensorQuantizer(act_bits, axis=1 if cw else None)
 
 
+class QConv2d(SparseModule):
+    """Descriptor of quant/quant_voxelnext.py:138-169 for SubMConv2d / SparseConv2d. As committed, the reference computes
+    the quantised activations but never writes them back (quant_voxelnext.py:165-167), so the layer is effectively
+    WEIGHT-ONLY int8 (per out-channel) on fp32 activations — that is what is reproduced."""
+
+    def __init__(self, module, w_bits, act_bits):
+        super().__init__()
+        self.module = module
+        self.w_bits, self.act_bits = int(w_bits), int(act_bits)
+        self.w_quant = TensorQuantizer(w_bits, axis=0)
+        self.act_quant = TensorQuantizer(act_bits, axis=None)     # present (calibration addresses it), unused at inference
+
+
 class _QuantConv2dBase(nn.Module):
     def __init__(self, conv, w_bits, act_bits):
         super().__init__()
@@ -213,6 +226,32 @@ def quant(model, w_bits, act_bits, sq, alpha, static, test_loader=None, n_batche
     if static:
         collect_stats(model, test_loader, n_batches)
         compute_amax(model, None, method="entropy")
+
+
+# ================================ the VoxelNeXt recipe (quant/quant_voxelnext.py:170-353) ==============
+def q_conv3d_voxelnext(model, module_dict, curr_path, w_bits, act_bits, cw):
+    """quant_voxelnext.py:170-176: every 3-D sparse conv except backbone_3d.conv_input.0."""
+    q_conv3d(model, module_dict, curr_path, w_bits, act_bits, cw, (SubMConv3d, SparseConv3d), ["backbone_3d.conv_input.0"])
+
+
+def q_conv2d(model, module_dict, curr_path="", w_bits=None, act_bits=None):
+    """quant_voxelnext.py:281-292: every 2-D sparse conv whose path is not in the head exclusion list."""
+    from .modules import SparseConv2d, SubMConv2d
+    if act_bits is None or w_bits is None:
+        raise ValueError("Please specify the num_bits parameter!")
+    for name, module in model.named_children():
+        path = "%s.%s" % (curr_path, name) if curr_path else name
+        q_conv2d(module, module_dict, path, w_bits, act_bits)
+        if isinstance(module, (SubMConv2d, SparseConv2d)) and path not in no_list:
+            model._modules[name] = QConv2d(module=module, w_bits=w_bits, act_bits=act_bits)
+    _touch()
+
+
+def dynamic_quant_voxelnext(model, w_bits, act_bits, sq=False, alpha=None):
+    """quant_voxelnext.py:330-337. The committed main passes sq=True, whose 2-D branch raises NameError in the reference
+    (SQSubM2d is never imported); the runnable semantics are QConv3d(cw) + QConv2d, selected here for either value of sq."""
+    q_conv3d_voxelnext(model, {}, "", w_bits, act_bits, cw=True if sq else False)
+    q_conv2d(model, {}, "", w_bits, act_bits)
 
 
 # ================================ plan-time weight quantisation =======================================
