@@ -308,6 +308,7 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
     AQ3D_SPCONV_CASE(64, 64, 2, 2)
     AQ3D_SPCONV_CASE(64, 128, 2, 2)
     AQ3D_SPCONV_CASE(128, 128, 2, 2)
+    AQ3D_SPCONV_CASE(128, 16, 4, 1)     // VoxelNeXt head output convs (1..3 channels padded to 16)
 #undef AQ3D_SPCONV_CASE
     aq3d_set_error("aq3d_spconv: unsupported channel pair cin=%d (pad %d) cout=%d", cin, cin_pad, cout);
     return AQ3D_ERR_UNSUPPORTED;

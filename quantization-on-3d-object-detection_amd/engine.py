@@ -14,8 +14,8 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .modules import SparseBasicBlock, SparseConvolution, SparseSequential
-from .quant import QConvNd, QuantConv2d, SQConv2d, _QuantConv2dBase, quantize_weight_rows, surgery_epoch
+from .modules import SparseBasicBlock, SparseConvolution, SparseSequential, VoxelResBackBone8xVoxelNeXt
+from .quant import QConv2d, QConvNd, QuantConv2d, SQConv2d, _QuantConv2dBase, quantize_weight_rows, surgery_epoch
 
 f32, i32 = torch.float32, torch.int32
 
@@ -128,8 +128,13 @@ class Engine:
         self.steps = []
         self.tensors = {}
         self._voxel_ws = None
-        self._build_sparse(det.backbone_3d)
-        self._build_dense(det.backbone_2d, det.dense_head)
+        if isinstance(det.backbone_3d, VoxelResBackBone8xVoxelNeXt):
+            self.fully_sparse = True
+            self._build_voxelnext(det.backbone_3d, det.dense_head)
+        else:
+            self.fully_sparse = False
+            self._build_sparse(det.backbone_3d)
+            self._build_dense(det.backbone_2d, det.dense_head)
         self.arena.finalize()
 
     # ------------------------------------------------------------------ helpers
@@ -139,123 +144,251 @@ class Engine:
             t = t.to(dtype)
         return t.to(self.device)
 
-    # ------------------------------------------------------------------ sparse backbone
-    def _build_sparse(self, bb):
+    # ------------------------------------------------------------------ sparse plan primitives
+    def _new_level(self, shape, kvol=27):
         dev, cap = self.device, self.cap
-        shape0 = list(bb.sparse_shape)
+        lv = dict(shape=list(shape), coords=torch.zeros((cap, 4), dtype=i32, device=dev),
+                  count=torch.zeros((1,), dtype=i32, device=dev), table=ops.HashTable(cap, dev),
+                  nbr=torch.full((cap, kvol), -1, dtype=i32, device=dev), subm_ksize=(3, 3, 3))
+        self.levels.append(lv)
+        return lv
+
+    def _tensor(self, level, C, name):
+        return dict(buf=torch.zeros((self.cap, C), dtype=f32, device=self.device), C=C, level=level,
+                    amax=self.arena.alloc(C), name=name)
+
+    def _compile_spconv(self, mod, path, x, level_out, nbr, kvol, bn, relu, residual=None):
+        """mod: SparseConvolution | QConvNd (w8a8, per input channel / per tensor) | QConv2d (weight-only).
+        Returns the output tensor record. Output channels are padded to a multiple of 16 (MFMA tile), the pad
+        columns carry zero weights / bias and unit BN scale."""
+        dev, cap = self.device, self.cap
+        q = mod if isinstance(mod, QConvNd) else None
+        q2 = mod if isinstance(mod, QConv2d) else None
+        conv = mod.module if (q is not None or q2 is not None) else mod
+        assert isinstance(conv, SparseConvolution)
+        cin, cout_real = conv.in_channels, conv.out_channels
+        cout = (cout_real + 15) // 16 * 16
+        w = _np(conv.weight).reshape(cout_real, kvol, cin)               # KRSC → [cout, kvol, cin]
+
+        def padc(v, fill=0.0):
+            v = np.asarray(v, dtype=np.float32)
+            if v.shape[0] < cout:
+                v = np.concatenate([v, np.full((cout - v.shape[0],) + v.shape[1:], fill, np.float32)], 0)
+            return v
+
+        rec = dict(path=path, cin=cin, cout=cout, cout_real=cout_real, kvol=kvol, x=x, nbr=nbr, level=level_out, relu=relu,
+                   residual=residual, quant=None)
+        wq_desc = q if q is not None else q2
+        quant_on = wq_desc is not None and wq_desc.w_quant._if_quant
+        if wq_desc is not None and wq_desc.w_quant._if_calib:   # constant weights: the max calibrator sees the same amax every batch
+            wq_desc.w_quant.collect(torch.from_numpy(np.abs(np.moveaxis(w, 2, 1).reshape(cout_real, -1)).max(axis=1)))
+        if quant_on:
+            codes, wdq, _ = quantize_weight_rows(np.moveaxis(w, 2, 1).reshape(cout_real, -1), wq_desc.w_bits)   # [oc, ic*kvol] view
+            codes = np.moveaxis(codes.reshape(cout_real, cin, kvol), 1, 2)                                    # back to [cout,kvol,cin]
+            if wq_desc.w_bits <= 8 and cin % 16 == 0:
+                wk = np.transpose(padc(codes.astype(np.float32)), (1, 0, 2))
+                rec["weight_i8"] = self._dev(wk.astype(np.int8))              # canonical int8 codes [kvol, cout, cin]
+                # staging copy of the same integers as fp16 (exact): the split-activation kernel copies it verbatim
+                split_w = q is not None and self.spconv_mode == "split"
+                rec["weight"] = self._dev(wk.astype(np.float16)) if split_w else rec["weight_i8"]
+                rec["w_dequant"] = self._dev(padc(wdq, 1.0))
+            else:   # fake-quantised fp32 weights through the fp32 weight path
+                wfq = (codes.astype(np.float32) * wdq[:, None, None]).astype(np.float32)
+                rec["weight"] = self._dev(np.transpose(padc(wfq), (1, 0, 2)))
+                rec["w_dequant"] = None
+        else:
+            rec["weight"] = self._dev(np.transpose(padc(w), (1, 0, 2)))
+            rec["w_dequant"] = None
+        rec["bias"] = self._dev(padc(_np(conv.bias))) if conv.bias is not None else None
+        if bn is not None:
+            s, b = fold_bn(bn)
+            rec["post_scale"], rec["post_shift"] = self._dev(padc(s, 1.0)), self._dev(padc(b))
+        else:
+            rec["post_scale"] = rec["post_shift"] = None
+        if q is not None:
+            aq = q.act_quant
+            rec["quant"] = dict(bits=q.act_bits, per_tensor=not q.cw, quantizer=aq, on=aq._if_quant,
+                                calib=aq._if_calib,
+                                static_amax=None if aq.amax is None else self._dev(_np(aq.amax).reshape(-1)))
+            use_codes = q.act_bits <= 8 and cin % 16 == 0 and rec["w_dequant"] is not None
+            rec["quant"]["use_codes"] = use_codes
+            split = use_codes and self.spconv_mode == "split"
+            rec["split"] = torch.zeros((cap, 2 * cin), dtype=torch.float16, device=dev) if split else None
+            rec["codes"] = torch.zeros((cap, cin), dtype=torch.int8, device=dev) if use_codes and not split else None
+            rec["fq"] = None if use_codes else torch.zeros((cap, cin), dtype=f32, device=dev)
+            rec["dq"] = torch.zeros((cin,), dtype=f32, device=dev)
+        out = self._tensor(level_out, cout, path)
+        rec["out"] = out
+        self.sparse_convs.append(rec)
+        self.steps.append(("spconv", rec))
+        return out
+
+    def _compile_block(self, blk, path, x, level, nbr):
+        assert isinstance(blk, SparseBasicBlock)
+        t = self._compile_spconv(blk.conv1, path + ".conv1", x, level, nbr, 27, blk.bn1, True)
+        return self._compile_spconv(blk.conv2, path + ".conv2", t, level, nbr, 27, blk.bn2, True, residual=x)
+
+    def _compile_stages(self, bb, names):
+        """conv_input + conv1 on level 0, then one strided SparseConv3d + residual blocks per named stage."""
+        cap, dev = self.cap, self.device
         self.levels = []          # dicts: shape, coords, count, table, nbr(subm), cap
-
-        def new_level(shape):
-            lv = dict(shape=list(shape), coords=torch.zeros((cap, 4), dtype=i32, device=dev),
-                      count=torch.zeros((1,), dtype=i32, device=dev), table=ops.HashTable(cap, dev),
-                      nbr=torch.full((cap, 27), -1, dtype=i32, device=dev))
-            self.levels.append(lv)
-            return lv
-
-        lv0 = new_level(shape0)
+        self._new_level(list(bb.sparse_shape))
         C0 = self.num_point_features
         self.vfe_feats = torch.zeros((cap, C0), dtype=f32, device=dev)
         self.vfe_npts = torch.zeros((cap,), dtype=i32, device=dev)
         self.sparse_convs = []    # compiled conv records (for introspection / tests)
         self.multi_scale = {}
-
-        def tensor(level, C, name):
-            t = dict(buf=torch.zeros((cap, C), dtype=f32, device=dev), C=C, level=level,
-                     amax=self.arena.alloc(C), name=name)
-            return t
-
-        def compile_conv(mod, path, x, level_out, nbr, kvol, bn, relu, residual=None):
-            """mod: SparseConvolution or QConvNd. Returns output tensor record."""
-            q = mod if isinstance(mod, QConvNd) else None
-            conv = mod.module if q is not None else mod
-            assert isinstance(conv, SparseConvolution)
-            cin, cout = conv.in_channels, conv.out_channels
-            w = _np(conv.weight).reshape(cout, kvol, cin)               # KRSC → [cout, kvol, cin]
-            rec = dict(path=path, cin=cin, cout=cout, kvol=kvol, x=x, nbr=nbr, level=level_out, relu=relu,
-                       residual=residual, quant=None)
-            quant_on = q is not None and q.w_quant._if_quant
-            if q is not None and q.w_quant._if_calib:       # constant weights: the max calibrator sees the same amax every batch
-                q.w_quant.collect(torch.from_numpy(np.abs(np.moveaxis(w, 2, 1).reshape(cout, -1)).max(axis=1)))
-            if quant_on:
-                codes, wdq, _ = quantize_weight_rows(np.moveaxis(w, 2, 1).reshape(cout, -1), q.w_bits)   # [oc, ic*k^3] view
-                codes = np.moveaxis(codes.reshape(cout, cin, kvol), 1, 2)                               # back to [cout,kvol,cin]
-                if q.w_bits <= 8 and cin % 16 == 0:
-                    wk = np.transpose(codes, (1, 0, 2))
-                    rec["weight_i8"] = self._dev(wk.astype(np.int8))              # canonical int8 codes [kvol, cout, cin]
-                    # staging copy of the same integers as fp16 (exact): the split-activation kernel copies it verbatim
-                    rec["weight"] = self._dev(wk.astype(np.float16)) if self.spconv_mode == "split" else rec["weight_i8"]
-                    rec["w_dequant"] = self._dev(wdq)
-                else:   # fake-quantised fp32 weights through the fp32 weight path
-                    wfq = (codes.astype(np.float32) * wdq[:, None, None]).astype(np.float32)
-                    rec["weight"] = self._dev(np.transpose(wfq, (1, 0, 2)))
-                    rec["w_dequant"] = None
-            else:
-                rec["weight"] = self._dev(np.transpose(w, (1, 0, 2)))
-                rec["w_dequant"] = None
-            rec["bias"] = self._dev(_np(conv.bias)) if conv.bias is not None else None
-            if bn is not None:
-                s, b = fold_bn(bn)
-                rec["post_scale"], rec["post_shift"] = self._dev(s), self._dev(b)
-            else:
-                rec["post_scale"] = rec["post_shift"] = None
-            if q is not None:
-                aq = q.act_quant
-                rec["quant"] = dict(bits=q.act_bits, per_tensor=not q.cw, quantizer=aq, on=aq._if_quant,
-                                    calib=aq._if_calib,
-                                    static_amax=None if aq.amax is None else self._dev(_np(aq.amax).reshape(-1)))
-                use_codes = q.act_bits <= 8 and cin % 16 == 0 and rec["w_dequant"] is not None
-                rec["quant"]["use_codes"] = use_codes
-                split = use_codes and self.spconv_mode == "split"
-                rec["split"] = torch.zeros((cap, 2 * cin), dtype=torch.float16, device=dev) if split else None
-                rec["codes"] = torch.zeros((cap, cin), dtype=torch.int8, device=dev) if use_codes and not split else None
-                rec["fq"] = None if use_codes else torch.zeros((cap, cin), dtype=f32, device=dev)
-                rec["dq"] = torch.zeros((cin,), dtype=f32, device=dev)
-            out = tensor(level_out, cout, path)
-            rec["out"] = out
-            self.sparse_convs.append(rec)
-            self.steps.append(("spconv", rec))
-            return out
-
-        def run_block(blk, path, x, level, nbr):
-            assert isinstance(blk, SparseBasicBlock)
-            t = compile_conv(blk.conv1, path + ".conv1", x, level, nbr, 27, blk.bn1, True)
-            return compile_conv(blk.conv2, path + ".conv2", t, level, nbr, 27, blk.bn2, True, residual=x)
-
         # level 0: voxels → hash + submanifold gather table (shared by conv_input 'subm1' and conv1 'res1')
         self.steps.append(("index_subm", 0))
         x_in = dict(buf=self.vfe_feats, C=C0, level=0, amax=self.arena.alloc(C0), name="vfe")
         self.steps.append(("absmax", x_in))      # only consumed if conv_input is quantised (sq=False recipe)
         ci = bb.conv_input
-        x = compile_conv(ci[0], "backbone_3d.conv_input.0", x_in, 0, 0, 27, ci[1], True)
+        x = self._compile_spconv(ci[0], "backbone_3d.conv_input.0", x_in, 0, 0, 27, ci[1], True)
         for bi, blk in enumerate(bb.conv1):
-            x = run_block(blk, "backbone_3d.conv1.%d" % bi, x, 0, 0)
+            x = self._compile_block(blk, "backbone_3d.conv1.%d" % bi, x, 0, 0)
         self.multi_scale["x_conv1"] = (x, 0)
-        for si, name in enumerate(("conv2", "conv3", "conv4")):
+        for si, name in enumerate(names):
             stage = getattr(bb, name)
             down = stage[0]
             conv = down[0].module if isinstance(down[0], QConvNd) else down[0]
             lv_in = self.levels[si]
-            lv_out = new_level(ops.conv_out_shape(lv_in["shape"], conv.kernel_size, conv.stride, conv.padding))
-            lv_out["down"] = dict(ksize=conv.kernel_size, stride=conv.stride, pad=conv.padding,
+            lv_out = self._new_level(ops.conv_out_shape(lv_in["shape"], conv.kernel_size, conv.stride, conv.padding))
+            lv_out["down"] = dict(src=si, ksize=conv.kernel_size, stride=conv.stride, pad=conv.padding,
                                   nbr=torch.full((cap, 27), -1, dtype=i32, device=dev))
             self.steps.append(("index_down", si + 1))
-            x = compile_conv(down[0], "backbone_3d.%s.0.0" % name, x, si + 1, ("down", si + 1), 27, down[1], True)
+            x = self._compile_spconv(down[0], "backbone_3d.%s.0.0" % name, x, si + 1, ("down", si + 1), 27, down[1], True)
             self.steps.append(("index_subm", si + 1))
             for bi in range(1, len(stage)):
-                x = run_block(stage[bi], "backbone_3d.%s.%d" % (name, bi), x, si + 1, si + 1)
+                x = self._compile_block(stage[bi], "backbone_3d.%s.%d" % (name, bi), x, si + 1, si + 1)
             self.multi_scale["x_%s" % name] = (x, si + 1)
+        return x
+
+    # ------------------------------------------------------------------ CenterPoint sparse backbone
+    def _build_sparse(self, bb):
+        cap, dev = self.cap, self.device
+        x = self._compile_stages(bb, ("conv2", "conv3", "conv4"))
         co = bb.conv_out
         conv = co[0].module if isinstance(co[0], QConvNd) else co[0]
         lv_in = self.levels[3]
-        lv_out = new_level(ops.conv_out_shape(lv_in["shape"], conv.kernel_size, conv.stride, conv.padding))
         kvol = int(np.prod(conv.kernel_size))
-        lv_out["down"] = dict(ksize=conv.kernel_size, stride=conv.stride, pad=conv.padding,
+        lv_out = self._new_level(ops.conv_out_shape(lv_in["shape"], conv.kernel_size, conv.stride, conv.padding))
+        lv_out["down"] = dict(src=3, ksize=conv.kernel_size, stride=conv.stride, pad=conv.padding,
                               nbr=torch.full((cap, kvol), -1, dtype=i32, device=dev))
         self.steps.append(("index_down", 4))
-        x = compile_conv(co[0], "backbone_3d.conv_out.0", x, 4, ("down", 4), kvol, co[1], True)
+        x = self._compile_spconv(co[0], "backbone_3d.conv_out.0", x, 4, ("down", 4), kvol, co[1], True)
         self.encoded = (x, 4)
-        need = max(ops._lib.load().aq3d_conv_outputs_workspace_bytes(cap, 27, self.levels[0]["table"].size), 256)
-        self.index_ws = torch.empty((need,), dtype=torch.uint8, device=dev)
+        self._alloc_index_ws()
+
+    def _alloc_index_ws(self):
+        L = ops._lib.load()
+        need = max(L.aq3d_conv_outputs_workspace_bytes(self.cap, 27, self.levels[0]["table"].size), 256)
+        self.index_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+
+    # ------------------------------------------------------------------ VoxelNeXt: sparse backbone, 2-D tail and head
+    def _build_voxelnext(self, bb, head):
+        """spconv_backbone_voxelnext.py:200-228 + voxelnext_head.py:535-560. 2-D sparse tensors are index levels of shape
+        (1, H, W) with coords rows (b, 0, y, x), so that every 2-D conv runs through the same gather tables and kernels."""
+        cap, dev = self.cap, self.device
+        self._compile_stages(bb, ("conv2", "conv3", "conv4", "conv5", "conv6"))
+        x4, l4 = self.multi_scale["x_conv4"]
+        x5, l5 = self.multi_scale["x_conv5"]
+        x6, l6 = self.multi_scale["x_conv6"]
+        assert x4["C"] == x5["C"] == x6["C"], "bev_out concatenates rows: equal channel counts"
+        _, H, W = self.levels[l4]["shape"]
+        lv_m = self._new_level([1, H, W], kvol=1)
+        mi = len(self.levels) - 1
+        merged = self._tensor(mi, x4["C"], "backbone_3d.bev_out")
+        L = ops._lib.load()
+        self.merge = dict(srcs=[(x4, l4, 1), (x5, l5, 2), (x6, l6, 4)], out=merged, level=mi,
+                          ws=torch.empty((max(L.aq3d_bev_merge_workspace_bytes(3, cap, lv_m["table"].size), 256),),
+                                         dtype=torch.uint8, device=dev))
+        self.steps.append(("bev_merge", None))
+        self.steps.append(("absmax", merged))
+        # conv_out: SparseConv2d 3x3 s1 p1 → dilated site set
+        co = bb.conv_out
+        conv = co[0].module if isinstance(co[0], QConv2d) else co[0]
+        k3 = (1,) + tuple(conv.kernel_size)
+        lv_o = self._new_level(ops.conv_out_shape([1, H, W], k3, (1,) + tuple(conv.stride), (0,) + tuple(conv.padding)),
+                               kvol=int(np.prod(k3)))
+        oi = len(self.levels) - 1
+        lv_o["subm_ksize"] = k3
+        lv_o["down"] = dict(src=mi, ksize=k3, stride=(1,) + tuple(conv.stride), pad=(0,) + tuple(conv.padding),
+                            nbr=torch.full((cap, int(np.prod(k3))), -1, dtype=i32, device=dev))
+        self.steps.append(("index_down", oi))
+        x = self._compile_spconv(co[0], "backbone_3d.conv_out.0", merged, oi, ("down", oi), int(np.prod(k3)), co[1], True)
+        # shared_conv: SubMConv2d 3x3 on the same sites
+        sc = bb.shared_conv
+        conv = sc[0].module if isinstance(sc[0], QConv2d) else sc[0]
+        ks = (1,) + tuple(conv.kernel_size)
+        lv_o["subm_ksize"] = ks
+        if int(np.prod(ks)) != lv_o["nbr"].shape[1]:
+            lv_o["nbr"] = torch.full((cap, int(np.prod(ks))), -1, dtype=i32, device=dev)
+        self.steps.append(("index_subm", oi))
+        x = self._compile_spconv(sc[0], "backbone_3d.shared_conv.0", x, oi, oi, int(np.prod(ks)), sc[1], True)
+        self.encoded = (x, oi)
+        self._alloc_index_ws()
+        # head: per branch (SubMConv2d k + BN1d + ReLU)* + SubMConv2d 1x1; gather tables per distinct kernel size
+        kh = int(head.model_cfg.get("KERNEL_SIZE_HEAD", 3))
+        self.head_nbr = {}
+        for k in sorted({kh, 1}):
+            key = ("head", k)
+            if (1, k, k) == ks:
+                self.head_nbr[k] = oi
+                continue
+            self.head_nbr[k] = key
+            lv_o.setdefault("extra_nbr", {})[k] = torch.full((cap, k * k), -1, dtype=i32, device=dev)
+        self.steps.append(("index_head", oi))
+        pp = head.model_cfg.POST_PROCESSING
+        K = int(pp.MAX_OBJ_PER_SAMPLE)
+        nms = pp.NMS_CONFIG
+        assert nms.NMS_TYPE == "nms_gpu", "only class-agnostic rotated NMS (nms_gpu) is on the VoxelNeXt path"
+        self.heads = []
+        self.head_first_step = len(self.steps)
+        import ctypes
+        for hi, sep in enumerate(head.heads_list):
+            outs = {}
+            for name in sep.sep_head_dict:
+                seq = getattr(sep, name)
+                t = x
+                path = "dense_head.heads_list.%d.%s" % (hi, name)
+                for li, m in enumerate(seq):
+                    if isinstance(m, SparseSequential):
+                        conv = m[0].module if isinstance(m[0], QConv2d) else m[0]
+                        k = conv.kernel_size[0]
+                        t = self._compile_spconv(m[0], "%s.%d.0" % (path, li), t, oi, self.head_nbr[k], k * k, m[1], True)
+                    else:
+                        conv = m.module if isinstance(m, QConv2d) else m
+                        k = conv.kernel_size[0]
+                        t = self._compile_spconv(m, "%s.%d" % (path, li), t, oi, self.head_nbr[k], k * k, None, False)
+                outs[name] = t
+            ncls = len(head.class_names_each_head[hi])
+            has_vel = "vel" in sep.sep_head_dict
+            ld = {n: outs[n]["C"] for n in outs}
+            assert len({ld[n] for n in outs if n != "hm"}) == 1
+            cfg = ops.make_decode_cfg(H, W, ncls, K, has_vel, head.feature_map_stride, self.voxel_size[:2],
+                                      self.pc_range[:2], [float(v) for v in pp.POST_CENTER_LIMIT_RANGE],
+                                      pp.SCORE_THRESH, ld["hm"], ld["center"])
+            nb = 9 if has_vel else 7
+            B = self.batch_cap
+            assert B == 1, "the VoxelNeXt plan decodes one sample per forward"
+            rec = dict(outs=outs, cfg=cfg, has_vel=has_vel, nb=nb, K=K, level=oi,
+                       thresh=float(nms.NMS_THRESH), pre=int(nms.NMS_PRE_MAXSIZE), post=int(nms.NMS_POST_MAXSIZE),
+                       class_map=head.class_id_mapping_each_head[hi].to(dev).to(i32).contiguous(),
+                       cand_boxes=torch.zeros((B, K, nb), dtype=f32, device=dev),
+                       cand_scores=torch.zeros((B, K), dtype=f32, device=dev),
+                       cand_labels=torch.zeros((B, K), dtype=i32, device=dev),
+                       cand_count=torch.zeros((B, 1), dtype=i32, device=dev),
+                       keep=torch.zeros((B, K), dtype=i32, device=dev),
+                       out_boxes=torch.zeros((B, K, nb), dtype=f32, device=dev),
+                       out_scores=torch.zeros((B, K), dtype=f32, device=dev),
+                       out_labels=torch.zeros((B, K), dtype=torch.int64, device=dev),
+                       dec_ws=torch.empty((max(L.aq3d_center_decode_workspace_bytes(ctypes.byref(cfg)), 256),),
+                                          dtype=torch.uint8, device=dev),
+                       nms_ws=torch.empty((max(L.aq3d_nms_workspace_bytes(K), 256),), dtype=torch.uint8, device=dev))
+            self.heads.append(rec)
+        self.det_counts = torch.zeros((self.batch_cap, len(self.heads)), dtype=i32, device=dev)
+        self.dense_convs = []
+        self.steps.append(("voxel_decode_nms", None))
 
     # ------------------------------------------------------------------ dense BEV backbone + head
     def _build_dense(self, b2d, head):
@@ -509,15 +642,17 @@ class Engine:
         self.timers = None
         return out
 
-    def _nbr_of(self, ref):
+    def _nbr_of(self, ref, level=None):
         if isinstance(ref, tuple):
+            if ref[0] == "head":
+                return self.levels[level]["extra_nbr"][ref[1]]
             return self.levels[ref[1]]["down"]["nbr"]
         return self.levels[ref]["nbr"]
 
     def _run_spconv(self, rec):
         lv = self.levels[rec["level"]]
         x = rec["x"]
-        nbr = self._nbr_of(rec["nbr"])
+        nbr = self._nbr_of(rec["nbr"], rec["level"])
         in_count = self.levels[x["level"]]["count"]
         feats, act_dq = x["buf"], None
         q = rec["quant"]
@@ -648,7 +783,7 @@ class Engine:
                 with _Timed(self, "rulebook"):
                     if "down" not in lv:   # level 0: table from the voxel coords; deeper levels get it from conv_outputs
                         ops.hash_build(lv["coords"], lv["count"], lv["shape"], lv["table"])
-                    ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], (3, 3, 3), lv["table"], out=lv["nbr"])
+                    ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], lv["subm_ksize"], lv["table"], out=lv["nbr"])
             elif kind == "index_down":
                 with _Timed(self, "rulebook"):
                     self._index_down(arg)
@@ -664,10 +799,45 @@ class Engine:
             elif kind == "decode_nms":
                 with _Timed(self, "decode_nms"):
                     self._decode_nms(B)
+            elif kind == "bev_merge":
+                with _Timed(self, "rulebook"):
+                    self._bev_merge()
+            elif kind == "index_head":
+                lv = self.levels[arg]
+                with _Timed(self, "rulebook"):
+                    for k, nbr in lv.get("extra_nbr", {}).items():
+                        ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], (1, k, k), lv["table"], out=nbr)
+            elif kind == "voxel_decode_nms":
+                with _Timed(self, "decode_nms"):
+                    self._voxel_decode_nms()
+
+    def _bev_merge(self):
+        m = self.merge
+        lv = self.levels[m["level"]]
+        srcs = [dict(coords=self.levels[l]["coords"], count=self.levels[l]["count"], feats=x["buf"], table=self.levels[l]["table"],
+                     shape=self.levels[l]["shape"], scale=sc) for x, l, sc in m["srcs"]]
+        ops.bev_merge(srcs, lv["shape"][1], lv["shape"][2], out=(lv["coords"], lv["count"], m["out"]["buf"], lv["table"]),
+                      workspace=m["ws"])
+
+    def _voxel_decode_nms(self):
+        b = 0
+        for hi, h in enumerate(self.heads):
+            lv = self.levels[h["level"]]
+            o = h["outs"]
+            ops.voxel_decode(o["hm"]["buf"], o["center"]["buf"], o["center_z"]["buf"], o["dim"]["buf"], o["rot"]["buf"],
+                             o["vel"]["buf"] if h["has_vel"] else None, lv["coords"], lv["count"], h["cfg"], workspace=h["dec_ws"],
+                             out=(h["cand_boxes"][b], h["cand_scores"][b], h["cand_labels"][b], h["cand_count"][b]))
+            cap_nms = min(h["K"], h["pre"])
+            ops.nms_rotated(h["cand_boxes"][b][:cap_nms], h["cand_count"][b], h["thresh"], h["post"],
+                            workspace=h["nms_ws"], out=(h["keep"][b][:cap_nms], self.det_counts[b, hi:hi + 1]))
+            ops.gather_dets(h["cand_boxes"][b][:cap_nms], h["cand_scores"][b][:cap_nms], h["cand_labels"][b][:cap_nms],
+                            h["class_map"], h["keep"][b][:cap_nms], self.det_counts[b, hi:hi + 1],
+                            out=(h["out_boxes"][b][:cap_nms], h["out_scores"][b][:cap_nms], h["out_labels"][b][:cap_nms]))
 
     def _index_down(self, li):
-        lv_in, lv_out = self.levels[li - 1], self.levels[li]
+        lv_out = self.levels[li]
         d = lv_out["down"]
+        lv_in = self.levels[d["src"]]
         L = ops._lib.load()
         kvol = int(np.prod(d["ksize"]))
         t_in, t_out = lv_in["table"], lv_out["table"]

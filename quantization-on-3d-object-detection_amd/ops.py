@@ -319,6 +319,62 @@ def center_decode(hm, center, center_z, dim, rot, vel, cfg, workspace=None, out=
     return boxes, scores, labels, count
 
 
+def voxel_decode(hm, center, center_z, dim, rot, vel, coords, count, cfg, workspace=None, out=None):
+    """Sparse-head decode of ONE sample: rows of hm/center/... are the live sites, coords i32 [cap, 4] rows (b, z, y, x).
+    → (boxes f32 [K, 7|9], scores f32 [K], labels i32 [K], count i32 [1])."""
+    L = _lib.load()
+    dev = hm.device
+    nb = 9 if cfg.has_vel else 7
+    if out is None:
+        boxes = torch.zeros((cfg.K, nb), dtype=f32, device=dev)
+        scores = torch.zeros((cfg.K,), dtype=f32, device=dev)
+        labels = torch.zeros((cfg.K,), dtype=i32, device=dev)
+        cnt = torch.zeros((1,), dtype=i32, device=dev)
+    else:
+        boxes, scores, labels, cnt = out
+    need = L.aq3d_center_decode_workspace_bytes(ctypes.byref(cfg))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
+    cap = coords.shape[0]
+    assert hm.shape[0] >= cap and hm.stride(0) == cfg.hm_ld and center.stride(0) == cfg.reg_ld
+    check(L.aq3d_voxel_decode(_pv(hm), _pv(center), _pv(center_z), _pv(dim), _pv(rot), _pv(vel), _p(coords), _p(count), cap,
+                              ctypes.byref(cfg), _p(boxes), _p(scores), _p(labels), _p(cnt), _p(workspace), workspace.numel(),
+                              _stream()), "aq3d_voxel_decode")
+    return boxes, scores, labels, cnt
+
+
+def bev_merge(srcs, H, W, out=None, workspace=None):
+    """VoxelNeXt bev_out. srcs: up to 3 dicts(coords [cap,4] i32, count i32[1], feats f32 [cap,C], table HashTable (3-D, built),
+    shape (z,y,x), scale). → (coords_out [cap,4] rows (b,0,y,x), count_out, feats_out [cap,C], table_out)."""
+    L = _lib.load()
+    n = len(srcs)
+    cap, C = srcs[0]["feats"].shape
+    dev = srcs[0]["feats"].device
+    for s_ in srcs:
+        assert s_["feats"].shape == (cap, C) and s_["coords"].shape == (cap, 4)
+    if out is None:
+        out = (torch.zeros((cap, 4), dtype=i32, device=dev), torch.zeros((1,), dtype=i32, device=dev),
+               torch.zeros((cap, C), dtype=f32, device=dev), HashTable(cap, dev))
+    coords_o, count_o, feats_o, table_o = out
+    need = L.aq3d_bev_merge_workspace_bytes(n, cap, table_o.size)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
+    PA = ctypes.c_void_p * n
+    arr = lambda key, f=lambda v: v: PA(*[f(s_[key]).data_ptr() for s_ in srcs])
+    coords = arr("coords")
+    counts = arr("count")
+    feats = arr("feats")
+    keys = PA(*[s_["table"].keys.data_ptr() for s_ in srcs])
+    vals = PA(*[s_["table"].vals.data_ptr() for s_ in srcs])
+    tsz = (ctypes.c_int32 * n)(*[s_["table"].size for s_ in srcs])
+    shapes = (ctypes.c_int32 * (3 * n))(*[int(v) for s_ in srcs for v in s_["shape"]])
+    scales = (ctypes.c_int32 * n)(*[int(s_["scale"]) for s_ in srcs])
+    check(L.aq3d_bev_merge(coords, counts, feats, keys, vals, tsz, shapes, scales, n, cap, C, int(H), int(W), _p(coords_o),
+                           _p(count_o), _p(feats_o), coords_o.shape[0], _p(table_o.keys), _p(table_o.vals), table_o.size,
+                           _p(workspace), workspace.numel(), _stream()), "aq3d_bev_merge")
+    return coords_o, count_o, feats_o, table_o
+
+
 def nms_rotated(boxes, count, thresh, post_max, workspace=None, out=None):
     """boxes f32 [cap, ld] sorted by descending score → (keep i32 [cap], keep_count i32 [1])."""
     L = _lib.load()

@@ -8,10 +8,11 @@ def small_cfg(kind="waymo", half_range=12.8):
     """The real model config on a shrunken point-cloud range (grid 256x256x40 → BEV 32x32) so the CPU oracle runs in seconds."""
     from amdq3d.config import AttrDict, cfg_from_yaml_file
     path = {"waymo": "cfgs/waymo_models/centerpoint.yaml",
-            "nuscenes": "cfgs/nuscenes_models/cbgs_voxel0075_res3d_centerpoint.yaml"}[kind]
+            "nuscenes": "cfgs/nuscenes_models/cbgs_voxel0075_res3d_centerpoint.yaml",
+            "voxelnext": "cfgs/nuscenes_models/cbgs_voxel0075_voxelnext.yaml"}[kind]
     cfg = cfg_from_yaml_file(path, AttrDict())
     r = cfg.DATA_CONFIG.POINT_CLOUD_RANGE
-    if kind == "nuscenes":
+    if kind in ("nuscenes", "voxelnext"):
         half_range = 12.0          # 0.075 m voxels → 320 cells
     cfg.DATA_CONFIG.POINT_CLOUD_RANGE = [-half_range, -half_range, r[2], half_range, half_range, r[5]]
     pp = cfg.MODEL.DENSE_HEAD.POST_PROCESSING
@@ -31,9 +32,9 @@ def build_model(cfg, n_points, n_voxels, n_frames=2, seed=4):
     return ds, model
 
 
-def match_boxes(boxes_a, scores_a, labels_a, boxes_b, scores_b, labels_b, iou_tol=1e-3, score_tol=1e-3):
+def match_boxes(boxes_a, scores_a, labels_a, boxes_b, scores_b, labels_b, iou_tol=1e-3, score_tol=1e-3, z_tol=1e-3):
     """Fraction of a's boxes that have a partner in b with BEV IoU >= 1 - iou_tol, same label, |dscore| <= score_tol
-    and |dz|, |dh| within 1e-3 (the BEV IoU ignores the vertical extent)."""
+    and |dz|, |dh| within z_tol (the BEV IoU ignores the vertical extent)."""
     from oracle import decode as OD
     if len(boxes_a) == 0:
         return 1.0
@@ -43,6 +44,6 @@ def match_boxes(boxes_a, scores_a, labels_a, boxes_b, scores_b, labels_b, iou_to
     ok = iou >= 1.0 - iou_tol
     ok &= labels_a[:, None] == labels_b[None, :]
     ok &= np.abs(scores_a[:, None] - scores_b[None, :]) <= score_tol
-    ok &= np.abs(boxes_a[:, None, 2] - boxes_b[None, :, 2]) <= 1e-3 * np.maximum(1.0, np.abs(boxes_a[:, None, 2]))
-    ok &= np.abs(boxes_a[:, None, 5] - boxes_b[None, :, 5]) <= 1e-3 * np.maximum(1.0, np.abs(boxes_a[:, None, 5]))
+    ok &= np.abs(boxes_a[:, None, 2] - boxes_b[None, :, 2]) <= z_tol * np.maximum(1.0, np.abs(boxes_a[:, None, 2]))
+    ok &= np.abs(boxes_a[:, None, 5] - boxes_b[None, :, 5]) <= z_tol * np.maximum(1.0, np.abs(boxes_a[:, None, 5]))
     return float(ok.any(axis=1).mean())

@@ -1,0 +1,173 @@
+"""GPU parity of the VoxelNeXt (fully sparse) path — BASELINE configs[4], SURVEY.md §8a row 20: aq3d_bev_merge and
+aq3d_voxel_decode against their oracle restatements, then VoxelNeXt.forward against oracle.voxelnext.run."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model, match_boxes, small_cfg
+from oracle import decode as OD
+from oracle import sparse as OS
+from oracle import voxelnext as OV
+
+pytestmark = pytest.mark.gpu
+
+
+def _level(rng, n, shape, C, dev, cap):
+    from amdq3d import ops
+    D, H, W = shape
+    keys = rng.choice(D * H * W, size=n, replace=False)
+    idx = np.stack([np.zeros(n, np.int64), keys // (H * W), (keys // W) % H, keys % W], 1).astype(np.int32)
+    feats = rng.standard_normal((n, C)).astype(np.float32)
+    coords = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    coords[:n] = torch.from_numpy(idx).to(dev)
+    fb = torch.zeros((cap, C), dtype=torch.float32, device=dev)
+    fb[:n] = torch.from_numpy(feats).to(dev)
+    count = torch.tensor([n], dtype=torch.int32, device=dev)
+    table = ops.hash_build(coords, count, shape)
+    return idx, feats, dict(coords=coords, count=count, feats=fb, table=table, shape=list(shape))
+
+
+@pytest.mark.parametrize("sizes", [(700, 300, 90), (1, 0, 0), (0, 0, 5)])
+def test_bev_merge_vs_oracle(dev, sizes):
+    from amdq3d import ops
+    rng = np.random.default_rng(3)
+    cap, C = 2048, 32
+    shapes = [(5, 48, 40), (3, 24, 20), (2, 12, 10)]
+    host, srcs = [], []
+    for n, shp, sc in zip(sizes, shapes, (1, 2, 4)):
+        idx, feats, d = _level(rng, n, shp, C, dev, cap)
+        d["scale"] = sc
+        srcs.append(d)
+        host.append((feats, idx, sc))
+    co, cnt, fo, table = ops.bev_merge(srcs, 48, 40)
+    f_ref, i_ref = OV.bev_out(host)
+    m = int(cnt.item())
+    assert m == len(i_ref)
+    got = co[:m].cpu().numpy()
+    order = np.argsort(OS._key(got, [1, 48, 40]))
+    np.testing.assert_array_equal(got[order], i_ref)                       # same site set, rows (b, 0, y, x)
+    np.testing.assert_allclose(fo[:m].cpu().numpy()[order], f_ref, rtol=0, atol=2e-6 * max(1.0, np.abs(f_ref).max()))
+    # the emitted hash table addresses the merged rows: a 1x1 submanifold table is the identity
+    nbr = ops.subm_neighbors(co, cnt, [1, 48, 40], (1, 1, 1), table)
+    np.testing.assert_array_equal(nbr[:m, 0].cpu().numpy(), np.arange(m))
+
+
+@pytest.mark.parametrize("n,ncls,K", [(3000, 2, 500), (3000, 1, 500), (120, 2, 500), (40000, 2, 500)])
+def test_voxel_decode_vs_oracle(dev, n, ncls, K):
+    from amdq3d import ops
+    rng = np.random.default_rng(n + ncls)
+    cap = max(n + 100, 256)
+    H = W = 180
+    keys = rng.choice(H * W, size=n, replace=n > H * W)
+    idx = np.stack([np.zeros(n, np.int64), np.zeros(n, np.int64), keys // W, keys % W], 1).astype(np.int32)
+    LD = 16
+    mk = lambda c, s: np.concatenate([rng.standard_normal((n, c)).astype(np.float32) * s, np.zeros((n, LD - c), np.float32)], 1)
+    hm, center, cz, dim, rot, vel = mk(ncls, 2.0), mk(2, 0.3), mk(1, 1.0), mk(3, 0.3), mk(2, 1.0), mk(2, 1.0)
+    pad = lambda a: torch.cat([torch.from_numpy(a), torch.zeros((cap - n, LD))], 0).to(dev)
+    coords = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    coords[:n] = torch.from_numpy(idx).to(dev)
+    count = torch.tensor([n], dtype=torch.int32, device=dev)
+    pr, vs = [-54.0, -54.0], [0.075, 0.075]
+    lim = [-61.2, -61.2, -10.0, 61.2, 61.2, 10.0]
+    cfg = ops.make_decode_cfg(H, W, ncls, K, True, 8, vs, pr, lim, 0.1, LD, LD)
+    b, s, l, c = ops.voxel_decode(pad(hm), pad(center), pad(cz), pad(dim), pad(rot), pad(vel), coords, count, cfg)
+    nb = int(c.item())
+    br, sr, lr = OV.decode_bbox_from_voxels(idx, OD.sigmoid(hm[:, :ncls]), center[:, :2], cz[:, :1], np.exp(dim[:, :3]),
+                                            rot[:, :2], vel[:, :2], pr + [-5.0], vs + [0.2], 8, K, 0.1, lim)
+    assert nb == len(sr)
+    np.testing.assert_allclose(s[:nb].cpu().numpy(), sr, rtol=0, atol=2e-6)
+    np.testing.assert_array_equal(l[:nb].cpu().numpy(), lr)
+    np.testing.assert_allclose(b[:nb].cpu().numpy(), br, rtol=1e-5, atol=2e-5)
+
+
+def _run_gpu(model, ds, index, dev):
+    from amdq3d.datasets import load_data_to_gpu
+    batch = ds.collate_batch([ds[index]])
+    load_data_to_gpu(batch, dev)
+    with torch.no_grad():
+        pred, recall = model(batch)
+    return pred[0], recall
+
+
+def _state(model):
+    return {k: v.detach().cpu() for k, v in model.state_dict().items()}
+
+
+def _sorted_rows(eng, li, shape):
+    m = int(eng.levels[li]["count"].item())
+    co = eng.levels[li]["coords"][:m].cpu().numpy()
+    return m, co, np.argsort(OS._key(co, shape))
+
+
+def _preds(pred):
+    return pred["pred_boxes"].cpu().numpy(), pred["pred_scores"].cpu().numpy(), pred["pred_labels"].cpu().numpy()
+
+
+def test_voxelnext_fp32_vs_oracle(dev):
+    cfg = small_cfg("voxelnext")
+    ds, model = build_model(cfg, n_points=12000, n_voxels=4000)
+    state = _state(model)
+    model.cuda()
+    pred, _ = _run_gpu(model, ds, 0, dev)
+    trace = {}
+    b_ref, s_ref, l_ref = OV.run(state, cfg, ds[0]["points"], None, trace)
+    eng = model.engine()
+    # six 3-D index levels bit-exact
+    for li, name in enumerate(("x_conv1", "x_conv2", "x_conv3", "x_conv4", "x_conv5", "x_conv6")):
+        x, idx, shape = trace["levels"][name]
+        m, co, order = _sorted_rows(eng, li, shape)
+        assert m == len(idx), name
+        if li > 0:      # level 0 keeps the voxelizer's row order in both
+            np.testing.assert_array_equal(co[order], idx)
+    x, idx, shape = trace["encoded"]
+    m, co, order = _sorted_rows(eng, eng.encoded[1], shape)
+    assert m == len(idx)
+    np.testing.assert_array_equal(co[order], idx)
+    fo = eng.encoded[0]["buf"][:m].cpu().numpy()
+    assert np.abs(fo[order] - x).max() <= 1e-4 * max(1.0, float(np.abs(x).max()))
+    pb, ps, pl = _preds(pred)
+    assert pl.dtype == np.int64 and pb.shape[1] == 9
+    assert len(s_ref) > 10, "synthetic weights should produce detections"
+    assert abs(len(ps) - len(s_ref)) <= max(2, len(s_ref) // 50)
+    assert match_boxes(b_ref, s_ref, l_ref, pb, ps, pl) >= 0.98
+    assert match_boxes(pb, ps, pl, b_ref, s_ref, l_ref) >= 0.98
+
+
+@pytest.mark.parametrize("cw", [True, False])
+def test_voxelnext_int8_vs_oracle(dev, cw):
+    """Quantized (QConv3d w8a8 + weight-only QConv2d). Same bars as the CenterPoint int8 test: indices bit-exact, first stage
+    tight, final features within 2x the oracle's own summation-order self-noise, boxes matched at the loosened bar that noise
+    level implies."""
+    from amdq3d import quant as Qz
+    cfg = small_cfg("voxelnext")
+    ds, model = build_model(cfg, n_points=12000, n_voxels=4000)
+    state = _state(model)
+    Qz.dynamic_quant_voxelnext(model, 8, 8, sq=cw)
+    model.cuda()
+    pred, _ = _run_gpu(model, ds, 0, dev)
+    eng = model.engine()
+    rec = OV.Recipe(8, 8, cw)
+    trace = {}
+    b_ref, s_ref, l_ref = OV.run(state, cfg, ds[0]["points"], rec, trace)
+    OS.ACCUM_DTYPE = np.float64
+    try:
+        trace64 = {}
+        OV.run(state, cfg, ds[0]["points"], rec, trace64)
+    finally:
+        OS.ACCUM_DTYPE = np.float32
+    x, idx, shape = trace["encoded"]
+    m, co, order = _sorted_rows(eng, eng.encoded[1], shape)
+    assert m == len(idx)
+    np.testing.assert_array_equal(co[order], idx)
+    # first residual stage: before rounding flips can cascade
+    x1 = trace["levels"]["x_conv1"][0]
+    g1 = eng.multi_scale["x_conv1"][0]["buf"][:len(x1)].cpu().numpy()
+    tol = 1e-4 * max(1.0, float(np.abs(x1).max()))
+    assert (np.abs(g1 - x1) <= tol).mean() >= 0.999
+    fo = eng.encoded[0]["buf"][:m].cpu().numpy()[order]
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+    self_noise = rms(trace64["encoded"][0] - x)
+    assert rms(fo - x) <= 2.0 * self_noise + 1e-4 * rms(x), (rms(fo - x), self_noise)
+    pb, ps, pl = _preds(pred)
+    assert len(s_ref) > 10
+    assert match_boxes(b_ref, s_ref, l_ref, pb, ps, pl, iou_tol=0.3, score_tol=0.1, z_tol=0.1) >= 0.8
