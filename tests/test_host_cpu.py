@@ -66,7 +66,8 @@ def _model(kind="waymo"):
     from amdq3d.config import AttrDict, cfg_from_yaml_file
     from amdq3d.datasets import SyntheticDataset
     from amdq3d.detector import build_network
-    path = {"waymo": "cfgs/waymo_models/centerpoint.yaml", "nuscenes": "cfgs/nuscenes_models/cbgs_voxel0075_res3d_centerpoint.yaml"}[kind]
+    path = {"waymo": "cfgs/waymo_models/centerpoint.yaml", "nuscenes": "cfgs/nuscenes_models/cbgs_voxel0075_res3d_centerpoint.yaml",
+            "voxelnext": "cfgs/nuscenes_models/cbgs_voxel0075_voxelnext.yaml"}[kind]
     cfg = cfg_from_yaml_file(path, AttrDict())
     ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_frames=1)
     return cfg, ds, build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
@@ -171,6 +172,48 @@ def test_quant_surgery_follows_the_reference_exclusion_lists():
     # calibration switches address quantizers by name suffix like quant/quantize.py:177-194
     names = [n for n, _ in m2.named_modules() if n.endswith("_quantizer") or n.endswith("_quant")]
     assert len(names) == 2 * 21 + 2 * 23
+
+
+def test_voxelnext_containers_and_quant_recipe():
+    """VoxelNeXt (BASELINE configs[4]): checkpoint key / shape contract of spconv_backbone_voxelnext.py:69-147 and
+    voxelnext_head.py:13-110, and the surgery of quant/quant_voxelnext.py:170-176,281-292."""
+    from amdq3d import quant as Q
+    from amdq3d.detector import VoxelNeXt
+    from amdq3d.modules import SparseConvolution
+    cfg, ds, m = _model("voxelnext")
+    assert isinstance(m, VoxelNeXt) and len(m.module_list) == 3 and m.backbone_3d.sparse_shape == [41, 1440, 1440]
+    sd = m.state_dict()
+    exp = {
+        "backbone_3d.conv_input.0.weight": (16, 3, 3, 3, 5), "backbone_3d.conv1.0.conv1.bias": (16,),
+        "backbone_3d.conv5.0.0.weight": (128, 3, 3, 3, 128), "backbone_3d.conv6.2.conv2.weight": (128, 3, 3, 3, 128),
+        "backbone_3d.conv_out.0.weight": (128, 3, 3, 128), "backbone_3d.conv_out.1.running_var": (128,),
+        "backbone_3d.shared_conv.0.weight": (128, 3, 3, 128), "backbone_3d.shared_conv.0.bias": (128,),
+        "backbone_3d.shared_conv.1.num_batches_tracked": (),
+        "dense_head.heads_list.0.center.0.0.weight": (128, 1, 1, 128), "dense_head.heads_list.0.center.0.0.bias": (128,),
+        "dense_head.heads_list.0.center.0.1.weight": (128,), "dense_head.heads_list.0.center.1.weight": (2, 1, 1, 128),
+        "dense_head.heads_list.1.hm.1.weight": (2, 1, 1, 128), "dense_head.heads_list.5.vel.1.bias": (2,),
+        "dense_head.heads_list.3.dim.1.weight": (3, 1, 1, 128),
+    }
+    for k, shp in exp.items():
+        assert k in sd and tuple(sd[k].shape) == shp, (k, tuple(sd[k].shape) if k in sd else None)
+    assert "backbone_3d.conv_out.0.bias" not in sd and "backbone_3d.conv2.0.0.bias" not in sd
+    assert m.backbone_3d.shared_conv[1].eps == 1e-5 and m.backbone_3d.conv_out[1].eps == 1e-3
+    assert float(m.dense_head.heads_list[2].hm[1].bias[0]) == pytest.approx(-2.19)
+    Q.dynamic_quant_voxelnext(m, 8, 8, sq=True)
+    mods = dict(m.named_modules())
+    assert isinstance(mods["backbone_3d.conv_input.0"], SparseConvolution)
+    q3 = [n for n, x in mods.items() if isinstance(x, Q.QConvNd)]
+    assert len(q3) == 4 + 5 * 5 and all(mods[n].cw for n in q3)
+    q2 = sorted(n for n, x in mods.items() if isinstance(x, Q.QConv2d))
+    assert "backbone_3d.conv_out.0" in q2 and "backbone_3d.shared_conv.0" in q2 and len(q2) == 2 + 6 * 5
+    for h in range(6):
+        assert isinstance(mods["dense_head.heads_list.%d.hm.0.0" % h], SparseConvolution)
+        assert isinstance(mods["dense_head.heads_list.%d.hm.1" % h], SparseConvolution)
+        assert isinstance(mods["dense_head.heads_list.%d.rot.1" % h], SparseConvolution)
+        assert isinstance(mods["dense_head.heads_list.%d.rot.0.0" % h], Q.QConv2d)
+    _, _, m2 = _model("voxelnext")
+    Q.dynamic_quant_voxelnext(m2, 8, 8, sq=False)
+    assert all(not x.cw for x in m2.modules() if isinstance(x, Q.QConvNd))
 
 
 def test_forward_needs_gpu_and_containers_have_no_torch_path():

@@ -155,3 +155,46 @@ def test_oracle_pipeline_deterministic_and_quant_loss_small():
     f8, f32_ = t8["spatial_features_2d"], t32["spatial_features_2d"]
     rel = float((f8 - f32_).pow(2).mean().sqrt() / f32_.pow(2).mean().sqrt())
     assert rel < 0.15                                                        # w8a8 keeps the BEV features within ~10 % rms
+
+
+def test_voxelnext_bev_out_and_decode_follow_the_reference_torch_ops():
+    """oracle.voxelnext.bev_out against the literal torch op sequence of spconv_backbone_voxelnext.py:149-198,214-221
+    (torch.unique(dim=0, return_inverse) + index_add_), and decode_bbox_from_voxels against torch.topk-based selection
+    (centernet_utils.py:243-272) on tie-free scores."""
+    import torch
+    from oracle import voxelnext as OV
+    rng = np.random.default_rng(7)
+    lv = []
+    for n, (D, H, W), sc in ((400, (5, 32, 32), 1), (150, (3, 16, 16), 2), (40, (2, 8, 8), 4)):
+        keys = rng.choice(D * H * W, n, replace=False)
+        idx = np.stack([rng.integers(0, 2, n), keys // (H * W), (keys // W) % H, keys % W], 1).astype(np.int32)
+        lv.append((rng.standard_normal((n, 8)).astype(np.float32), idx, sc))
+    f, i4 = OV.bev_out(lv)
+    feats = torch.cat([torch.from_numpy(a) for a, _, _ in lv])
+    ind = torch.cat([torch.from_numpy(np.concatenate([i[:, :1], i[:, 1:] * s], 1)) for _, i, s in lv])[:, [0, 2, 3]]
+    uq, inv = torch.unique(ind, dim=0, return_inverse=True)
+    ref = feats.new_zeros((uq.shape[0], 8))
+    ref.index_add_(0, inv, feats)
+    np.testing.assert_array_equal(i4[:, [0, 2, 3]], uq.numpy())
+    assert (i4[:, 1] == 0).all()
+    np.testing.assert_allclose(f, ref.numpy(), rtol=0, atol=1e-6)
+    # decode
+    n, C, K = 900, 2, 50
+    hm = rng.random((n, C)).astype(np.float32)
+    idx = np.stack([np.zeros(n), rng.integers(0, 40, n), rng.integers(0, 40, n)], 1).astype(np.int32)
+    center, cz, dim = rng.random((n, 2)).astype(np.float32), rng.random((n, 1)).astype(np.float32), rng.random((n, 3)).astype(np.float32) + 0.5
+    rot, vel = rng.standard_normal((n, 2)).astype(np.float32), rng.standard_normal((n, 2)).astype(np.float32)
+    b, s, l = OV.decode_bbox_from_voxels(idx, hm, center, cz, dim, rot, vel, [-12.0, -12.0, -5.0], [0.075, 0.075, 0.2], 8, K, 0.3,
+                                         [-20, -20, -10, 20, 20, 10])
+    th = torch.from_numpy(hm).permute(1, 0)
+    ts, ti = torch.topk(th, K)
+    fs, fi = torch.topk(ts.reshape(-1), K)
+    cls = (fi // K).numpy()
+    rows = ti.reshape(-1)[fi].numpy()
+    keep = fs.numpy() > 0.3
+    np.testing.assert_array_equal(s, fs.numpy()[keep])
+    np.testing.assert_array_equal(l, cls[keep])
+    xs = (idx[rows, 2] + center[rows, 0]) * np.float32(8) * np.float32(0.075) + np.float32(-12.0)
+    np.testing.assert_allclose(b[:, 0], xs[keep], rtol=0, atol=4e-6)     # my test line multiplies in another order
+    np.testing.assert_allclose(b[:, 6], np.arctan2(rot[rows, 1], rot[rows, 0])[keep], rtol=0, atol=1e-6)
+    assert b.shape[1] == 9
