@@ -23,23 +23,34 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 N_POINTS, N_VOXELS, N_FRAMES = 150000, 30000, 8
+WORKLOADS = {      # --workload → (cfg, points, voxels, description); the headline (BASELINE metric) is "centerpoint"
+    "centerpoint": ("cfgs/waymo_models/centerpoint.yaml", 150000, 30000,
+                    "Full CenterPoint VoxelNet sparse backbone + dense int8 BEV head, synthetic Waymo-shape 150k-pt / 30k-voxel "
+                    "frames (BASELINE configs[2]), SmoothQuant w8a8 dynamic, 1 frame/step/GPU"),
+    "voxelnext": ("cfgs/nuscenes_models/cbgs_voxel0075_voxelnext.yaml", 40000, 20000,
+                  "VoxelNeXt fully sparse int8 (quant/quant_voxelnext.py recipe: w8a8 per-channel 3-D convs + weight-only 2-D convs), "
+                  "synthetic nuScenes-shape 40k-pt / 20k-voxel frames (BASELINE configs[4]), 1 frame/step/GPU"),
+}
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_PEAK_TOPS = {"i8": 5000.0, "f16": 2500.0, "f32": 157.3}   # dense peaks: int8 = 2x f16/bf16 (2.5 PF); f32 MFMA = vector rate
 
 
-def build(cfg_path, dev):
+def build(cfg_path, dev, n_points=N_POINTS, n_voxels=N_VOXELS):
     from amdq3d import quant
     from amdq3d.config import AttrDict, cfg_from_yaml_file
     from amdq3d.datasets import SyntheticDataset
     from amdq3d.detector import build_network
     from amdq3d.synthetic import init_synthetic_weights
     cfg = cfg_from_yaml_file(cfg_path, AttrDict())
-    ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_frames=N_FRAMES, n_points=N_POINTS, n_voxels=N_VOXELS, seed0=4)
+    ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_frames=N_FRAMES, n_points=n_points, n_voxels=n_voxels, seed0=4)
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
     init_synthetic_weights(model, 4)
     model.eval()
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    quant.quant(model, 8, 8, sq=True, alpha=0.5, static=False)
+    if cfg.MODEL.NAME == "VoxelNeXt":
+        quant.dynamic_quant_voxelnext(model, 8, 8, sq=True)
+    else:
+        quant.quant(model, 8, 8, sq=True, alpha=0.5, static=False)
     model.voxel_capacity = int(os.environ.get("AQ3D_VOXEL_CAP", "65536"))
     model.to(dev)
     return cfg, ds, model, state
@@ -80,7 +91,7 @@ def kernel_work(eng, cat):
                 continue
             lv_out, lv_in = eng.levels[r["level"]], eng.levels[r["x"]["level"]]
             m_out, m_in = int(lv_out["count"].item()), int(lv_in["count"].item())
-            nbr = eng._nbr_of(r["nbr"])[:m_out]
+            nbr = eng._nbr_of(r["nbr"], r["level"])[:m_out]
             pairs = int((nbr >= 0).sum().item())
             # algorithmic activation bytes: the int8 code of the quantised input (1 B) or fp32 (4 B) — what the layer needs,
             # not what the chosen staging format (fp16 hi/lo pair) moves
@@ -96,13 +107,19 @@ def kernel_work(eng, cat):
 
 def cpu_baseline(cfg, ds, state):
     """The CPU oracle (a port, not the reference binary) on ONE frame of the same workload, host cores of this box."""
-    from oracle import centerpoint as OC
     pts = ds[0]["points"]
     t0 = time.time()
-    b, s, l = OC.run(state, cfg, pts, OC.Recipe(8, 8, True, 0.5))
+    if cfg.MODEL.NAME == "VoxelNeXt":
+        from oracle import voxelnext as OV
+        b, s, l = OV.run(state, cfg, pts, OV.Recipe(8, 8, True))
+        name = "oracle.voxelnext.run"
+    else:
+        from oracle import centerpoint as OC
+        b, s, l = OC.run(state, cfg, pts, OC.Recipe(8, 8, True, 0.5))
+        name = "oracle.centerpoint.run"
     dt = time.time() - t0
     return {"value": 1.0 / dt, "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "1 frame of W150k (150000 pts / 30000 voxels) through oracle.centerpoint.run, %.1f s, %d boxes" % (dt, len(s))}
+            "sample": "1 frame (%d pts) through %s, %.1f s, %d boxes" % (len(pts), name, dt, len(s))}
 
 
 def main():
@@ -110,7 +127,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--cfg", default="cfgs/waymo_models/centerpoint.yaml")
+    ap.add_argument("--workload", default="centerpoint", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="time every kernel family in an extra pass (stderr)")
     args = ap.parse_args()
@@ -125,7 +142,8 @@ def main():
     dev = torch.device("cuda", local)
     D.init("nccl")
     lib.load()
-    cfg, ds, model, state = build(args.cfg, dev)
+    cfg_path, n_points, n_voxels, wl_desc = WORKLOADS[args.workload]
+    cfg, ds, model, state = build(cfg_path, dev, n_points, n_voxels)
 
     # frames resident in HBM before the timed region; frame i → rank i mod world
     mine = D.frames_for_rank(max(N_FRAMES, world), rank, world) if world <= N_FRAMES else [rank % N_FRAMES]
@@ -197,13 +215,12 @@ def main():
             roof.update({"kernel": dominant, "launches_per_frame": n_launch, "avg_launch_us": avg_launch_s * 1e6,
                          "ms_per_frame": per_frame_ms})
         out = {
-            "metric": "frames/sec/GPU int8 CenterPoint @150k pts; mAP delta vs fp32 ref",
+            "metric": "frames/sec/GPU int8 CenterPoint @150k pts; mAP delta vs fp32 ref" if args.workload == "centerpoint"
+            else "frames/sec/GPU int8 VoxelNeXt @40k pts",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-            "config": {"workload": "Full CenterPoint VoxelNet sparse backbone + dense int8 BEV head, synthetic Waymo-shape "
-                                   "150k-pt / 30k-voxel frames (BASELINE configs[2]), SmoothQuant w8a8 dynamic, 1 frame/step/GPU",
-                       "frames": N_FRAMES, "points": N_POINTS, "voxels": N_VOXELS, "parallelism": "replicas(frames)x%d" % world,
+            "config": {"workload": wl_desc, "frames": N_FRAMES, "points": n_points, "voxels": n_voxels, "parallelism": "replicas(frames)x%d" % world,
                        "avg_boxes_per_frame": n_det / max(args.steps, 1)},
             "roofline": roof,
             "warmup_breakdown_ms_per_frame": {k: v[1] / n_warm for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},

@@ -22,7 +22,18 @@ import torch  # noqa: E402
 HBM_GBS, F16_TFLOPS = 8000.0, 2500.0
 
 
-def occupancy(kind, m, seed=4):
+def _morton_key(idx):
+    """Z-curve over (y>>3, x>>3) tiles, then z, y, x inside — the row order a spatial sort of the voxels would give."""
+    ty, tx = idx[:, 2].astype(np.int64) >> 3, idx[:, 3].astype(np.int64) >> 3
+    key = np.zeros(len(idx), np.int64)
+    for b in range(9):
+        key |= ((tx >> b) & 1) << (2 * b)
+        key |= ((ty >> b) & 1) << (2 * b + 1)
+    inner = ((idx[:, 1].astype(np.int64) * 8) + (idx[:, 2] & 7)) * 8 + (idx[:, 3] & 7)
+    return key * 4096 + inner
+
+
+def occupancy(kind, m, seed=4, order="random"):
     """i32 [m, 4] active sites (b, z, y, x) inside a [41, 1504, 1504] grid."""
     rng = np.random.default_rng(seed)
     if kind == "sheet":          # contiguous ground sheet, 3 z-levels: ~13 of 27 neighbours active (LiDAR-like surfaces)
@@ -43,6 +54,10 @@ def occupancy(kind, m, seed=4):
         _, c, _ = V.voxelize_mean(pts, pr, vs, 5, 10 ** 9)
         idx = c.astype(np.int64)
     idx = idx[rng.permutation(len(idx))]
+    if order == "morton":
+        idx = idx[np.argsort(_morton_key(idx), kind="stable")]
+    elif order == "linear":
+        idx = idx[np.lexsort((idx[:, 3], idx[:, 2], idx[:, 1]))]
     return idx.astype(np.int32)
 
 
@@ -52,6 +67,7 @@ def main():
     ap.add_argument("--voxels", type=int, nargs="+", default=[30000, 120000, 480000, 1000000])
     ap.add_argument("--occupancy", default="sheet")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--order", default="random", choices=["random", "morton", "linear"], help="row order of the voxels")
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle on the smallest size")
     args = ap.parse_args()
     from amdq3d import ops
@@ -59,7 +75,7 @@ def main():
     dev = torch.device("cuda:0")
     shape = [41, 1504, 1504]
     for m_req in args.voxels:
-        idx = occupancy(args.occupancy, m_req)
+        idx = occupancy(args.occupancy, m_req, order=args.order)
         m = len(idx)
         cap = m
         coords = torch.from_numpy(idx).to(dev)
@@ -96,7 +112,7 @@ def main():
             us = e0.elapsed_time(e1) * 1e3 / args.iters
             byts = m * C * 4 + m * C * 1 + m * C * 4 + 27 * C * C + m * 27 * 4      # fp32 in (quantiser) + codes + fp32 out + w + table
             flops = 2.0 * pairs * C * C
-            rec = {"layer": "SubMConv3d 3x3x3 %d->%d int8-w x per-channel-quantised a" % (C, C), "occupancy": args.occupancy,
+            rec = {"layer": "SubMConv3d 3x3x3 %d->%d int8-w x per-channel-quantised a" % (C, C), "occupancy": args.occupancy, "order": args.order,
                    "voxels": m, "pairs": pairs, "us_per_layer": us, "algorithmic_GBps": byts / us / 1e3,
                    "frac_hbm": byts / us / 1e3 / HBM_GBS, "useful_TFLOPs": flops / us / 1e6,
                    "frac_mfma_f16": flops / us / 1e6 / F16_TFLOPS, "voxels_per_s": m / us * 1e6}

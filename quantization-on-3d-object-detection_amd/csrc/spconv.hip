@@ -253,6 +253,10 @@ int aq3d_spconv_direct_dispatch(const void *feats_split, unsigned feats_bytes, c
                                 const float *bias, const float *post_scale, const float *post_shift, const float *residual,
                                 const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
                                 float *feats_out, float *absmax_out, hipStream_t stream);
+int aq3d_spconv_wide_dispatch(const void *feats_split, unsigned feats_bytes, const void *weight_f16, const float *w_dequant,
+                              const float *bias, const float *post_scale, const float *post_shift, const float *residual,
+                              const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
+                              float *feats_out, float *absmax_out, hipStream_t stream);
 int aq3d_spconv_split_dispatch(const void *feats_split, unsigned feats_bytes, const void *weight_f16, const float *w_dequant,
                                const float *bias, const float *post_scale, const float *post_shift, const float *residual,
                                const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
@@ -278,6 +282,10 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
             int rc = aq3d_spconv_direct_dispatch(feats_in, (unsigned)((int64_t)cap_in * cin * 4), weight, w_dequant, bias,
                                                  post_scale, post_shift, residual, nbr, count_out, cap_out, cin, cout, kvol,
                                                  (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, stream);
+            if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
+            rc = aq3d_spconv_wide_dispatch(feats_in, (unsigned)((int64_t)cap_in * cin * 4), weight, w_dequant, bias,
+                                           post_scale, post_shift, residual, nbr, count_out, cap_out, cin, cout, kvol,
+                                           (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, stream);
             if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
         }
         return aq3d_spconv_split_dispatch(feats_in, (unsigned)((int64_t)cap_in * cin * 4), weight, w_dequant, bias, post_scale,

@@ -299,12 +299,6 @@ int aq3d_spconv_split_dispatch(const void *feats_split, unsigned feats_bytes, co
     AQ3D_SPLIT_CASE(16, 32, 2, 2, 9, 1)
     AQ3D_SPLIT_CASE(32, 32, 2, 2, 4, 1)
     AQ3D_SPLIT_CASE(32, 64, 2, 2, 4, 1)
-    static const bool wide = getenv("AQ3D_SPCONV_WIDE") != nullptr && atoi(getenv("AQ3D_SPCONV_WIDE")) != 0;   // measured: no gain
-    if (wide) {   // 8-wave workgroups (64 rows): same registers per wave, half the weight re-streaming per output row
-        AQ3D_SPLIT_CASE(64, 64, 4, 2, 2, 1)
-        AQ3D_SPLIT_CASE(64, 128, 4, 2, 2, 1)
-        AQ3D_SPLIT_CASE(128, 128, 4, 2, 1, 1)
-    }
     AQ3D_SPLIT_CASE(64, 64, 2, 2, 2, 1)
     AQ3D_SPLIT_CASE(64, 128, 2, 2, 2, 1)
     AQ3D_SPLIT_CASE(128, 128, 2, 2, 1, 1)

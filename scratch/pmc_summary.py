@@ -11,7 +11,7 @@ for d in sys.argv[1:]:
             if key not in seen and d == sys.argv[1]:
                 seen.add(key); calls[k] += 1
 names = sorted(agg, key=lambda k: -agg[k].get("SQ_BUSY_CYCLES", 0))
-cols = ["SQ_WAVE_CYCLES","SQ_BUSY_CYCLES","SQ_WAIT_ANY","SQ_WAIT_INST_ANY","SQ_ACTIVE_INST_ANY","SQ_ACTIVE_INST_VALU","SQ_ACTIVE_INST_LDS","SQ_VALU_MFMA_BUSY_CYCLES","SQ_INSTS_VALU","SQ_INSTS_MFMA","SQ_INSTS_LDS","SQ_LDS_BANK_CONFLICT","SQ_LDS_IDX_ACTIVE","SQ_INSTS_VMEM","SQ_WAIT_INST_LDS","FETCH_SIZE","WRITE_SIZE","TCC_HIT_sum","TCC_MISS_sum","GRBM_GUI_ACTIVE"]
+cols = ["SQ_WAVE_CYCLES","SQ_BUSY_CYCLES","SQ_WAIT_ANY","SQ_WAIT_INST_ANY","SQ_ACTIVE_INST_ANY","SQ_ACTIVE_INST_VALU","SQ_ACTIVE_INST_LDS","SQ_VALU_MFMA_BUSY_CYCLES","SQ_INSTS_VALU","SQ_INSTS_MFMA","SQ_INSTS_LDS","SQ_LDS_BANK_CONFLICT","SQ_LDS_IDX_ACTIVE","SQ_INSTS_VMEM","SQ_WAIT_INST_LDS","FETCH_SIZE","WRITE_SIZE","TCC_HIT_sum","TCC_MISS_sum","GRBM_GUI_ACTIVE"] + [c for c in sorted({c for k in agg for c in agg[k]}) if c.startswith(("TA_", "TCP_", "TCC_REQ", "TCC_READ", "TCC_EA", "TCC_TAG", "TCC_BUSY", "TD_"))]
 print("per-dispatch averages (counter sum / dispatches); FETCH/WRITE_SIZE in KB (FETCH_SIZE under-reads wide streams 2x on gfx950)")
 print("%-52s %5s " % ("kernel", "n") + " ".join("%12s" % c.replace("SQ_", "")[:12] for c in cols))
 for k in names[:40]:
