@@ -156,12 +156,7 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = (i32x4){0, 0, 0, 0};
 
-    load_step(0);
-    store_step(0);
-    __syncthreads();
-    for (int k = 0; k < nk; ++k) {
-        const int buf = k & 1;
-        if (k + 1 < nk) load_step(k + 1);
+    auto mma_step = [&](int buf) {
         i32x4 af[TI], bf[TJ];
 #pragma unroll
         for (int i = 0; i < TI; ++i)
@@ -174,9 +169,20 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < TJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
-        if (k + 1 < nk) store_step(buf ^ 1);
+    };
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    // branch-free steady state (the last step is peeled): conditionals around the loads / stores inside the loop made the
+    // compiler shuttle all accumulators between VGPRs and AGPRs every K step
+    for (int k = 0; k + 1 < nk; ++k) {
+        const int buf = k & 1;
+        load_step(k + 1);
+        mma_step(buf);
+        store_step(buf ^ 1);
         __syncthreads();
     }
+    mma_step((nk - 1) & 1);
 
     // epilogue: lane holds oc = base + 4g .. 4g+3 for pixel column l15
 #pragma unroll
@@ -306,12 +312,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    load_step(0);
-    store_step(0);
-    __syncthreads();
-    for (int k = 0; k < nk; ++k) {
-        const int buf = k & 1;
-        if (k + 1 < nk) load_step(k + 1);
+    auto mma_step = [&](int buf) {
         f32x4 af[TI], bf[TJ];
 #pragma unroll
         for (int i = 0; i < TI; ++i)
@@ -328,9 +329,18 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvArgs a) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
             }
-        if (k + 1 < nk) store_step(buf ^ 1);
+    };
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int k = 0; k + 1 < nk; ++k) {       // branch-free steady state, last step peeled (see conv2d_i8_kernel)
+        const int buf = k & 1;
+        load_step(k + 1);
+        mma_step(buf);
+        store_step(buf ^ 1);
         __syncthreads();
     }
+    mma_step((nk - 1) & 1);
 
     const int d = a.deconv;
 #pragma unroll

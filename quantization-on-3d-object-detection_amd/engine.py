@@ -136,6 +136,12 @@ class Engine:
             self._build_sparse(det.backbone_3d)
             self._build_dense(det.backbone_2d, det.dense_head)
         self.arena.finalize()
+        # second HIP stream for the index (rulebook) chain, see _run_steps; AQ3D_INDEX_STREAM=0 keeps everything on one stream
+        self.index_stream = None
+        if device.type == "cuda" and os.environ.get("AQ3D_INDEX_STREAM", "1") != "0":
+            self.index_stream = torch.cuda.Stream(device=device)
+            self._ev_main = torch.cuda.Event()
+            self._ev_idx = [torch.cuda.Event() for _ in range(16)]
 
     # ------------------------------------------------------------------ helpers
     def _dev(self, arr, dtype=None):
@@ -772,21 +778,37 @@ class Engine:
         self._run_steps(self.steps, B)
         return B
 
+    INDEX_KINDS = ("index_subm", "index_down", "index_head")
+
     def _run_steps(self, steps, B):
-        for kind, arg in steps:
+        """Walks the plan. Index generation (hash tables, gather tables, strided output sets) depends only on voxel
+        coordinates, never on features, so it runs on its own HIP stream ahead of the convolutions that consume it: the small
+        latency-bound rulebook kernels execute beside the previous level's convs instead of between them. Ordering is by
+        events: the index stream waits for whatever the main stream produced for it (voxelizer, bev_merge), the main stream
+        waits for the newest index event before the next kernel that might read a gather table."""
+        main = torch.cuda.current_stream(self.device)
+        side = self.index_stream
+        pending = None        # newest event recorded on the index stream that main has not waited for yet
+        if side is not None:
+            self._ev_main.record(main)      # everything enqueued so far on main (voxelizer / arena clear)
+            side.wait_event(self._ev_main)
+        for si, (kind, arg) in enumerate(steps):
+            if kind in self.INDEX_KINDS:
+                if side is None:
+                    self._run_index(kind, arg)
+                else:
+                    with torch.cuda.stream(side):
+                        self._run_index(kind, arg)
+                        pending = self._ev_idx[si % len(self._ev_idx)]
+                        pending.record(side)
+                continue
+            if pending is not None:
+                main.wait_event(pending)
+                pending = None
             if kind == "spconv":
                 self._run_spconv(arg)
             elif kind == "conv2d":
                 self._run_conv2d(arg, B)
-            elif kind == "index_subm":
-                lv = self.levels[arg]
-                with _Timed(self, "rulebook"):
-                    if "down" not in lv:   # level 0: table from the voxel coords; deeper levels get it from conv_outputs
-                        ops.hash_build(lv["coords"], lv["count"], lv["shape"], lv["table"])
-                    ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], lv["subm_ksize"], lv["table"], out=lv["nbr"])
-            elif kind == "index_down":
-                with _Timed(self, "rulebook"):
-                    self._index_down(arg)
             elif kind == "absmax":
                 if any(r["quant"] is not None and (r["quant"]["on"] or r["quant"]["calib"]) and r["x"] is arg
                        for r in self.sparse_convs):
@@ -802,14 +824,30 @@ class Engine:
             elif kind == "bev_merge":
                 with _Timed(self, "rulebook"):
                     self._bev_merge()
-            elif kind == "index_head":
-                lv = self.levels[arg]
-                with _Timed(self, "rulebook"):
-                    for k, nbr in lv.get("extra_nbr", {}).items():
-                        ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], (1, k, k), lv["table"], out=nbr)
+                if side is not None:            # the merged site set feeds the index steps that follow
+                    self._ev_main.record(main)
+                    side.wait_event(self._ev_main)
             elif kind == "voxel_decode_nms":
                 with _Timed(self, "decode_nms"):
                     self._voxel_decode_nms()
+        if pending is not None:
+            main.wait_event(pending)
+
+    def _run_index(self, kind, arg):
+        if kind == "index_subm":
+            lv = self.levels[arg]
+            with _Timed(self, "rulebook"):
+                if "down" not in lv:   # level 0: table from the voxel coords; deeper levels get it from conv_outputs
+                    ops.hash_build(lv["coords"], lv["count"], lv["shape"], lv["table"])
+                ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], lv["subm_ksize"], lv["table"], out=lv["nbr"])
+        elif kind == "index_down":
+            with _Timed(self, "rulebook"):
+                self._index_down(arg)
+        elif kind == "index_head":
+            lv = self.levels[arg]
+            with _Timed(self, "rulebook"):
+                for k, nbr in lv.get("extra_nbr", {}).items():
+                    ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], (1, k, k), lv["table"], out=nbr)
 
     def _bev_merge(self):
         m = self.merge
