@@ -166,17 +166,33 @@ def main():
     n_warm = max(args.warmup, 1)
     dominant = max(warm.items(), key=lambda kv: kv[1][1])[0] if warm else None
 
+    # graph warm-up (untimed): the first frames without per-kernel events capture the per-slot hipGraphs the timed region replays
+    for i in range(2 * eng.NSLOT):
+        step(i)
     D.barrier()
     torch.cuda.synchronize(dev)
-    eng.start_timing([dominant] if dominant else None)
     t0 = time.perf_counter()
+    # two frames in flight: frame i+1 is enqueued before the detections of frame i are read back (every frame is still
+    # completed and read inside this region)
     n_det = 0
+    prev = None
     for i in range(args.steps):
-        pred, _ = step(i)
-        n_det += int(pred[0]["pred_scores"].shape[0])
+        with torch.no_grad():
+            cur = model.forward_async(dict(batches[i % len(batches)]))
+        if prev is not None:
+            n_det += int(prev.counts().sum())
+        prev = cur
+    if prev is not None:
+        n_det += int(prev.counts().sum())
     torch.cuda.synchronize(dev)
     D.barrier()
     elapsed = time.perf_counter() - t0
+    # roofline leg: the same frames once more with HIP events around every launch of the dominant kernel family (events cannot
+    # bracket single kernels inside a replayed graph, so this pass enqueues eagerly; same kernels, same inputs, same stream)
+    n_roof = max(1, min(args.steps, 50))
+    eng.start_timing([dominant] if dominant else None)
+    for i in range(n_roof):
+        step(i)
     timed = eng.stop_timing()
     total_frames, tmax, fps = D.aggregate_throughput(args.steps, elapsed, dev)
 
@@ -185,7 +201,7 @@ def main():
         if dominant and dominant in timed:
             groups, ms = timed[dominant]
             byts, ops, n_launch = kernel_work(eng, dominant)
-            per_frame_ms = ms / max(args.steps, 1)
+            per_frame_ms = ms / n_roof
             avg_launch_s = per_frame_ms * 1e-3 / max(n_launch, 1)
             if dominant == "conv2d_i8":
                 ach = ops / n_launch / avg_launch_s / 1e12
@@ -223,6 +239,7 @@ def main():
             "config": {"workload": wl_desc, "frames": N_FRAMES, "points": n_points, "voxels": n_voxels, "parallelism": "replicas(frames)x%d" % world,
                        "avg_boxes_per_frame": n_det / max(args.steps, 1)},
             "roofline": roof,
+            "execution": "hipGraph replay, 2 frames in flight" if getattr(eng, "_graphs", None) else "eager launches, 2 frames in flight",
             "warmup_breakdown_ms_per_frame": {k: v[1] / n_warm for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
         }
         if world == 1 and not args.no_cpu_baseline:

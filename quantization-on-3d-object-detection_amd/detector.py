@@ -192,6 +192,22 @@ class Detector3DTemplate(nn.Module):
         return super()._apply(fn, *a, **k)
 
 
+class PendingFrame:
+    """Handle of an enqueued frame (Detector.forward_async)."""
+
+    def __init__(self, det, eng, slot, B, batch_dict):
+        self.det, self.eng, self.slot, self.B, self.batch_dict = det, eng, slot, B, batch_dict
+
+    def counts(self):
+        """Detections per (sample, head) — one event wait + a pinned-host read, no tensor slicing."""
+        return self.eng.counts(self.B, self.slot)
+
+    def result(self):
+        """→ (pred_dicts, recall_dict), exactly what Detector.forward returns."""
+        self.batch_dict["final_box_dicts"] = self.eng.collect(self.B, self.slot)
+        return self.det.post_processing(self.batch_dict)
+
+
 class CenterPoint(Detector3DTemplate):
     def __init__(self, model_cfg, num_class, dataset):
         super().__init__(model_cfg=model_cfg, num_class=num_class, dataset=dataset)
@@ -209,10 +225,16 @@ class CenterPoint(Detector3DTemplate):
         return self.post_processing(batch_dict)
 
     def forward_async(self, batch_dict):
-        """Enqueue a frame without reading anything back; returns the engine (padded outputs + device counts)."""
+        """Enqueue a frame without reading anything back → PendingFrame. Up to Engine.NSLOT frames may be in flight: enqueue
+        frame N+1, then call .result() of frame N (serving loops hide the host-side launch work behind the GPU this way)."""
+        if self.training:
+            raise NotImplementedError("inference-only build: call model.eval() (training is outside the hot path)")
+        B = int(batch_dict["batch_size"])
+        if B > self.max_batch_size:
+            self.max_batch_size = B
         eng = self.engine()
         eng.run(batch_dict)
-        return eng
+        return PendingFrame(self, eng, eng.slot, B, batch_dict)
 
     def post_processing(self, batch_dict):
         post_process_cfg = self.model_cfg.POST_PROCESSING
