@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void sq_weights_kernel(const float *__restrict
     float sx = __fdiv_rn(qmax_a, amax_x), dvx = sx;
     if (amax_x <= eps) { sx = 0.f; dvx = 1.f; }
     const float inv_sx = __fdiv_rn(1.0f, dvx);
-    if (oc == 0 && threadIdx.x == 0) { scal[0] = sx; scal[1] = amax_x; scal[2] = inv_sx; }
+    if (oc == 0 && threadIdx.x == 0) { scal[0] = sx; scal[1] = amax_x; scal[2] = inv_sx; scal[3] = static_amax_x > 0.f ? 1.f : 0.f; }
     const float *wrow = weight + (size_t)oc * K;
     float mx = 0.f;
     for (int j = threadIdx.x; j < K; j += 256) mx = fmaxf(mx, fabsf(__fmul_rn(wrow[j], s[j])));

@@ -35,6 +35,10 @@ class Detector3DTemplate(nn.Module):
         self.module_topology = ["vfe", "backbone_3d", "map_to_bev_module", "pfe", "backbone_2d", "dense_head",
                                 "point_head", "roi_head"]
         self._engine = None
+        self._extra_engines = []         # forward_async: further device plans, each on its own HIP stream (see async_streams)
+        self._rr = 0
+        import os
+        self.async_streams = int(os.environ.get("AQ3D_STREAMS", "1"))   # frames that execute concurrently under forward_async
         self.max_batch_size = 1          # engine buffers are sized for this many frames per forward
         self.voxel_capacity = None       # rows of the sparse buffers (default MAX_NUMBER_OF_VOXELS * max_batch_size)
         self.voxelize_on_device = True   # False: consume batch_dict['voxels'/'voxel_coords'] when present
@@ -185,10 +189,26 @@ class Detector3DTemplate(nn.Module):
         e = self._engine
         if e is None or e.epoch != surgery_epoch() or e.device != dev or e.batch_cap < self.max_batch_size:
             self._engine = Engine(self, dev)
+            self._extra_engines = []
         return self._engine
+
+    def _async_engine(self):
+        """Round-robin over async_streams device plans. Plan 0 is engine() (it keeps running on the caller's stream); the
+        others own their buffers and a HIP stream each, so that the latency-bound head and tail of one frame (voxelizer,
+        rulebook, small level-0 convs ... decode, NMS) execute beside the heavy middle of another."""
+        primary = self.engine()
+        n = max(1, int(self.async_streams))
+        while len(self._extra_engines) < n - 1:
+            e = Engine(self, primary.device)
+            e.stream = torch.cuda.Stream(device=primary.device)
+            self._extra_engines.append(e)
+        k = self._rr % n
+        self._rr += 1
+        return primary if k == 0 else self._extra_engines[k - 1]
 
     def _apply(self, fn, *a, **k):
         self._engine = None
+        self._extra_engines = []
         return super()._apply(fn, *a, **k)
 
 
@@ -232,8 +252,14 @@ class CenterPoint(Detector3DTemplate):
         B = int(batch_dict["batch_size"])
         if B > self.max_batch_size:
             self.max_batch_size = B
-        eng = self.engine()
-        eng.run(batch_dict)
+        eng = self._async_engine()
+        side = getattr(eng, "stream", None)
+        if side is None:
+            eng.run(batch_dict)
+        else:
+            side.wait_stream(torch.cuda.current_stream(eng.device))     # the inputs were produced on the caller's stream
+            with torch.cuda.stream(side):
+                eng.run(batch_dict)
         return PendingFrame(self, eng, eng.slot, B, batch_dict)
 
     def post_processing(self, batch_dict):
