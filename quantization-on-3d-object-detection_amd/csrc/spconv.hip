@@ -262,6 +262,67 @@ int aq3d_spconv_split_dispatch(const void *feats_split, unsigned feats_bytes, co
                                const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
                                float *feats_out, float *absmax_out, hipStream_t stream);
 
+// ---------------------------------------------------------------- stem layer (conv_input: Cin <= 8 raw point features -> 16)
+// K = 27 * Cin is ~135: far too thin for tiles, LDS staging and barriers (the generic kernel takes 42 us for 30 k rows, all of
+// it latency). Plain VALU instead: thread = one output row x 4 output channels (blockIdx.y = channel quad, so the 4*Cin
+// weights of a kernel offset are wave-uniform scalar operands), fp32 fma chain in (offset, channel) order — the same chain
+// as the MFMA kernel and the oracle's per-offset matmul.
+template <int CIN>
+__global__ __launch_bounds__(256) void spconv_stem_kernel(SpconvArgs a, int cout) {
+    int n = *a.count_out;
+    if (n > a.cap_out) n = a.cap_out;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int o0 = blockIdx.y * 4;
+    const float *x = static_cast<const float *>(a.feats_in);
+    const float *w = static_cast<const float *>(a.weight);        // [kvol][cout][CIN]
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < n) {
+        const int *nb = a.nbr + (size_t)row * a.kvol;
+        for (int k = 0; k < a.kvol; ++k) {
+            const int src = nb[k];
+            if (src < 0) continue;
+            float xv[CIN];
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) xv[c] = x[(size_t)src * CIN + c];
+            const float *wk = w + ((size_t)k * cout + o0) * CIN;    // wave-uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) t = __fmaf_rn(xv[c], wk[j * CIN + c], t);
+                acc[j] = __fadd_rn(acc[j], t);
+            }
+        }
+    }
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < n) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = o0 + j;
+            float v = acc[j];
+            if (a.bias) v = __fadd_rn(v, a.bias[o]);
+            if (a.post_scale) v = __fadd_rn(__fmul_rn(v, a.post_scale[o]), a.post_shift[o]);
+            if (a.residual) v = __fadd_rn(v, a.residual[(size_t)row * cout + o]);
+            if (a.relu) v = fmaxf(v, 0.f);
+            a.feats_out[(size_t)row * cout + o] = v;
+            mx[j] = fabsf(v);
+        }
+    }
+    if (a.absmax_out) {
+        __shared__ float red[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float m = aq3d_wave_max(mx[j]);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const float m = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+            if (m > a.absmax_out[o0 + threadIdx.x]) aq3d_atomic_max_pos(&a.absmax_out[o0 + threadIdx.x], m);
+        }
+    }
+}
+
 extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
                            int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
                            const float *post_shift, const float *residual, const int32_t *nbr,
@@ -306,6 +367,17 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
     a.bias = bias; a.post_scale = post_scale; a.post_shift = post_shift; a.residual = residual;
     a.nbr = nbr; a.count_out = count_out; a.feats_out = feats_out; a.absmax_out = absmax_out;
     a.cap_out = cap_out; a.cin = cin; a.kvol = kvol; a.relu = (flags & AQ3D_FLAG_RELU) ? 1 : 0;
+    static const bool no_stem = getenv("AQ3D_SPCONV_NO_STEM") != nullptr;
+    if (!no_stem && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && cin <= 8 && (cout & 3) == 0 && cout <= 64) {
+        const dim3 grid(aq3d_div_up(cap_out, 256), cout / 4);
+        switch (cin) {
+#define AQ3D_STEM(C_) case C_: hipLaunchKernelGGL(spconv_stem_kernel<C_>, grid, dim3(256), 0, stream, a, cout); break;
+            AQ3D_STEM(1) AQ3D_STEM(2) AQ3D_STEM(3) AQ3D_STEM(4) AQ3D_STEM(5) AQ3D_STEM(6) AQ3D_STEM(7) AQ3D_STEM(8)
+#undef AQ3D_STEM
+        }
+        AQ3D_CHECK_LAUNCH("aq3d_spconv(stem)");
+        return AQ3D_OK;
+    }
     const int cin_pad = (cin + 15) / 16 * 16;
 #define AQ3D_SPCONV_CASE(CP, CO, WR_, WC_) \
     if (cin_pad == CP && cout == CO) return spconv_launch_modes<CP, CO, WR_, WC_>(a, act_mode, w_mode, stream);

@@ -27,8 +27,11 @@ struct SpconvDirectArgs {
     unsigned feats_bytes;
 };
 
-template <int CIN, int COUT, int KVOL>
-__global__ __launch_bounds__(256) void spconv_direct_kernel(SpconvDirectArgs a) {
+// NW waves per workgroup share the LDS-resident weights; the kernel is bound by gather latency (rocprof: 83 % of the wave
+// cycles parked in s_waitcnt), so what matters is how many independent waves a CU holds: the weights cap it at 2 workgroups.
+template <int CIN, int COUT, int KVOL, int NW>
+__global__ __launch_bounds__(64 * NW) void spconv_direct_kernel(SpconvDirectArgs a) {
+    constexpr int NTH = 64 * NW, TMW = 16 * NW;
     constexpr int NT = COUT / 16;
     constexpr int KT = KVOL * CIN;                       // total K
     constexpr int NCH = (KT + 31) / 32;                  // 32-wide K chunks
@@ -43,12 +46,12 @@ __global__ __launch_bounds__(256) void spconv_direct_kernel(SpconvDirectArgs a) 
     const int g = lane >> 4, l15 = lane & 15;
     int n = *a.count_out;
     if (n > a.cap_out) n = a.cap_out;
-    const int ntiles = (n + 63) / 64;
+    const int ntiles = (n + TMW - 1) / TMW;
     const auto rsrc_f = __builtin_amdgcn_make_buffer_rsrc((void *)a.feats, 0, (int)a.feats_bytes, 0x00020000);
     const auto rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, a.cap_out * KVOL * 4, 0x00020000);
 
     // stage the whole weight tensor once: global [k][o][c] → Bs[o][k*CIN + c]; zero the K padding
-    for (int t = tid; t < COUT * (LD / 8); t += 256) {
+    for (int t = tid; t < COUT * (LD / 8); t += NTH) {
         const int o = t / (LD / 8), c8 = t % (LD / 8);
         const int kk = c8 * 8;                                       // K index of this 16-byte chunk
         i32x4v v = (i32x4v){0, 0, 0, 0};
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void spconv_direct_kernel(SpconvDirectArgs a) 
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int row = tile * 64 + wave * 16 + l15;                 // this lane's output row (4 g-groups share it)
+        const int row = tile * TMW + wave * 16 + l15;                 // this lane's output row (4 g-groups share it)
         // the row's KVOL neighbour indices, one dword load each (out-of-range rows read as 0 → treated as "no neighbour")
         int nb[KVOL];
 #pragma unroll
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void spconv_direct_kernel(SpconvDirectArgs a) 
             float mx = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = tile * 64 + wave * 16 + 4 * g + r;
+                const int m = tile * TMW + wave * 16 + 4 * g + r;
                 if (m < n) {
                     float v = __fadd_rn(acc_hi[nt][r], __fmul_rn(acc_lo[nt][r], 1.0f / 2048.f));
                     v = __fmul_rn(v, wdq);
@@ -139,23 +142,25 @@ __global__ __launch_bounds__(256) void spconv_direct_kernel(SpconvDirectArgs a) 
                 for (int nt = 0; nt < NT; ++nt) red[wave * COUT + nt * 16 + l15] = cmax[nt];
             }
             __syncthreads();
-            for (int o = tid; o < COUT; o += 256) {
-                const float mx = fmaxf(fmaxf(red[o], red[COUT + o]), fmaxf(red[2 * COUT + o], red[3 * COUT + o]));
+            for (int o = tid; o < COUT; o += NTH) {
+                float mx = red[o];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w * COUT + o]);
                 if (mx > a.absmax_out[o]) aq3d_atomic_max_pos(&a.absmax_out[o], mx);
             }
         }
     }
 }
 
-template <int CIN, int COUT, int KVOL>
+template <int CIN, int COUT, int KVOL, int NW>
 static int launch_direct(const SpconvDirectArgs &a, hipStream_t stream) {
     constexpr int NCH = (KVOL * CIN + 31) / 32;
-    constexpr size_t lds = (size_t)COUT * (NCH * 32 + 8) * 2 + 4 * COUT * 4;
-    const int tiles = aq3d_div_up(a.cap_out, 64);
+    constexpr size_t lds = (size_t)COUT * (NCH * 32 + 8) * 2 + NW * COUT * 4;
+    const int tiles = aq3d_div_up(a.cap_out, 16 * NW);
     const int grid = tiles < 2048 ? (tiles < 1 ? 1 : tiles) : 2048;      // persistent: each workgroup stages the weights once
-    auto kern = spconv_direct_kernel<CIN, COUT, KVOL>;
+    auto kern = spconv_direct_kernel<CIN, COUT, KVOL, NW>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
     AQ3D_CHECK_LAUNCH("aq3d_spconv(direct gather)");
     return AQ3D_OK;
 }
@@ -172,8 +177,18 @@ int aq3d_spconv_direct_dispatch(const void *feats_split, unsigned feats_bytes, c
     a.post_scale = post_scale; a.post_shift = post_shift; a.residual = residual; a.nbr = nbr; a.count_out = count_out;
     a.feats_out = feats_out; a.absmax_out = absmax_out; a.cap_out = cap_out; a.kvol = kvol; a.relu = relu;
     a.feats_bytes = feats_bytes;
-    if (cin == 16 && cout == 16) return launch_direct<16, 16, 27>(a, stream);
-    if (cin == 16 && cout == 32) return launch_direct<16, 32, 27>(a, stream);
-    if (cin == 32 && cout == 32) return launch_direct<32, 32, 27>(a, stream);
+    // 8-wave workgroups: measured on the W150k recipe 42 -> 33 us for 32->32 at 65 k rows (the dilated second level), but
+    // 23 -> 30 us at 30 k rows and slower for Cin 16 — so only the 32->32 layers (they run on the densest level) use them
+    static const int nw = getenv("AQ3D_DIRECT_WAVES") ? atoi(getenv("AQ3D_DIRECT_WAVES")) : 0;
+    if (nw >= 8 || nw == 0) {
+        if (cin == 32 && cout == 32) return launch_direct<32, 32, 27, 8>(a, stream);
+    }
+    if (nw >= 8) {
+        if (cin == 16 && cout == 16) return launch_direct<16, 16, 27, 8>(a, stream);
+        if (cin == 16 && cout == 32) return launch_direct<16, 32, 27, 8>(a, stream);
+    }
+    if (cin == 16 && cout == 16) return launch_direct<16, 16, 27, 4>(a, stream);
+    if (cin == 16 && cout == 32) return launch_direct<16, 32, 27, 4>(a, stream);
+    if (cin == 32 && cout == 32) return launch_direct<32, 32, 27, 4>(a, stream);
     return AQ3D_ERR_UNSUPPORTED;
 }
