@@ -125,21 +125,30 @@ __global__ __launch_bounds__(256) void spconv_wide_kernel(SpconvWideArgs a) {
             }
         }
     };
-    auto loadA = [&](i32x4v (&A)[RT][2][KC], int k, int h) {
+    // gather-table entries of this lane's RT rows for offset k (-1 past the last unit): read early, used by loadA later
+    auto readSrc = [&](int (&src)[RT], int k) {
         const int kk = k < kvol ? k : 0;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
-            int src = nbr_s[(wave * (RT * 16) + rt * 16 + l15) * kvol + kk];
-            src = k < kvol ? src : -1;
-            const unsigned base = (unsigned)src * (unsigned)(2 * CIN * 2) + (unsigned)((h * UC + 8 * g) * 2);
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-#pragma unroll
-                for (int kc = 0; kc < KC; ++kc) {
-                    const unsigned off = src >= 0 ? base + (unsigned)((half * CIN + kc * 32) * 2) : WD_OOB;
-                    A[rt][half][kc] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, off, 0, 0);
-                }
+            const int v = nbr_s[(wave * (RT * 16) + rt * 16 + l15) * kvol + kk];
+            src[rt] = k < kvol ? v : -1;
         }
+    };
+    auto loadA1 = [&](i32x4v (&A)[RT][2][KC], const int (&src)[RT], int h, int rt) {      // the 2*KC fragments of row tile rt
+        const unsigned base = (unsigned)src[rt] * (unsigned)(2 * CIN * 2) + (unsigned)((h * UC + 8 * g) * 2);
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) {
+                const unsigned off = src[rt] >= 0 ? base + (unsigned)((half * CIN + kc * 32) * 2) : WD_OOB;
+                A[rt][half][kc] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, off, 0, 0);
+            }
+    };
+    auto loadA = [&](i32x4v (&A)[RT][2][KC], int k, int h) {
+        int src[RT];
+        readSrc(src, k);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) loadA1(A, src, h, rt);
     };
     auto next_unit = [&](int &k, int &h) {            // advance (k, h) to the next unit with work; k = kvol at the end
         if (k >= kvol) return;
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(256) void spconv_wide_kernel(SpconvWideArgs a) {
     };
     const f16x8 lo_scale = {(_Float16)(1.0f / 2048.f), (_Float16)(1.0f / 2048.f), (_Float16)(1.0f / 2048.f), (_Float16)(1.0f / 2048.f),
                             (_Float16)(1.0f / 2048.f), (_Float16)(1.0f / 2048.f), (_Float16)(1.0f / 2048.f), (_Float16)(1.0f / 2048.f)};
-    long long st0 = 0, st1 = 0, st2 = 0, stn = 0;
+    long long st0 = 0, st1 = 0, st2 = 0, stn = 0, stf = 0;
     // One unit: MFMAs on Acur / LDS buffer b, with the next unit's traffic issued between the MFMA groups.
     auto unit = [&](i32x4v (&Acur)[RT][2][KC], i32x4v (&Anext)[RT][2][KC], int b, int &k, int &h) {
         const long long t0 = STAMP ? __builtin_amdgcn_s_memtime() : 0;
@@ -167,24 +176,29 @@ __global__ __launch_bounds__(256) void spconv_wide_kernel(SpconvWideArgs a) {
         // Weight fragments stream LDS -> registers three deep (an LDS read takes ~130-200 cycles, 4 MFMAs only 64), each one
         // feeds 4 MFMAs (2 row tiles x hi / lo). The scheduling fences keep this order; the next unit's gathers are issued
         // a quarter of the way in so that they land under the remaining MFMAs, the barrier and the head of the next unit.
+        const long long tf = STAMP ? __builtin_amdgcn_s_memtime() : 0;
+        if constexpr (STAMP) stf += tf - t0;
         constexpr int NF = KC * NT;                      // fragments per unit, j = kc * NT + nt
+        constexpr int FD = 4;                            // fragment reads in flight ahead of the MFMAs that use them
         const int c0 = SWZ ? (g ^ ((l15 >> 1) & 7)) : g;  // this lane's chunk of K chunk 0; K chunk 1 is c0 ^ 4 (swizzled) / c0 + 4
         const _Float16 *bb = Wb + (b * COUT + l15) * LDW;
         auto frag = [&](int j) {
             const int c = SWZ ? (c0 ^ ((j / NT) * 4)) : (c0 + (j / NT) * 4);
             return *reinterpret_cast<const f16x8 *>(bb + (j % NT) * 16 * LDW + c * 8);
         };
-        f16x8 fb[3];
-        fb[0] = frag(0);
-        fb[1] = frag(NF > 1 ? 1 : 0);
+        f16x8 fb[FD + 1];
+#pragma unroll
+        for (int j = 0; j < FD && j < NF; ++j) fb[j] = frag(j);
+        int src[RT];
+        readSrc(src, k);                                 // the next unit's gather rows: their LDS latency hides under group 0
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
-            if (j + 2 < NF) fb[(j + 2) % 3] = frag(j + 2);
-            if (j == NF / 4) loadA(Anext, k, h);
+            if (j + FD < NF) fb[(j + FD) % (FD + 1)] = frag(j + FD);
+            if (j >= 1 && j <= RT) loadA1(Anext, src, h, j - 1);     // one row tile's gathers per MFMA group, not one long bubble
             __builtin_amdgcn_sched_barrier(0);
             const int nt = j % NT, kc = j / NT;
-            const f16x8 f = fb[j % 3];
+            const f16x8 f = fb[j % (FD + 1)];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F[rt][0][kc], f, acc[rt][nt], 0, 0, 0);
 #pragma unroll
@@ -220,6 +234,7 @@ __global__ __launch_bounds__(256) void spconv_wide_kernel(SpconvWideArgs a) {
         atomicAdd((unsigned long long *)&a.stamps[4], (unsigned long long)(tloop - tstart));
         atomicAdd((unsigned long long *)&a.stamps[5], (unsigned long long)(__builtin_amdgcn_s_memtime() - tloop));
         atomicAdd((unsigned long long *)&a.stamps[6], 1ull);
+        atomicAdd((unsigned long long *)&a.stamps[7], (unsigned long long)stf);
     }
 
     // ---- epilogue (D layout: col = lane&15 -> out channel, row = 4g + reg -> tile row)
@@ -284,8 +299,8 @@ static int launch_wide(const SpconvWideArgs &a, hipStream_t stream, bool stamp) 
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(h, dev, 64, hipMemcpyDeviceToHost);
         const double nu = (double)(h[3] ? h[3] : 1), nw = (double)(h[6] ? h[6] : 1);
-        fprintf(stderr, "[wide %dx%d] units/wg %.1f  cycles/unit: mfma-seg %.0f  storeW %.0f  barrier %.0f | per wg: prologue %.0f  loop %.0f\n",
-                CIN, COUT, nu / nw, h[0] / nu, h[1] / nu, h[2] / nu, h[4] / nw, h[5] / nw);
+        fprintf(stderr, "[wide %dx%d] units/wg %.1f  cycles/unit: A-wait+scale %.0f  mfma-loop %.0f  storeW %.0f  barrier %.0f | per wg: prologue %.0f  loop %.0f\n",
+                CIN, COUT, nu / nw, h[7] / nu, (h[0] - h[7]) / nu, h[1] / nu, h[2] / nu, h[4] / nw, h[5] / nw);
         return AQ3D_OK;
     }
     hipLaunchKernelGGL(kern, dim3(grid < 1 ? 1 : grid), dim3(256), lds, stream, a);
