@@ -221,6 +221,69 @@ __global__ __launch_bounds__(256) void sq_weights_kernel(const float *__restrict
     if (threadIdx.x == 0) out_mul[oc] = __fmul_rn(inv_sx, __fdiv_rn(1.0f, dv));
 }
 
+// Fused form of the two kernels above, one launch per layer: every block (= one output channel) recomputes the K smoothing
+// scales from the 16 x Cin piece maxima (8 KB, L2-resident: ~20 flops per column, cheaper than a dependent second launch),
+// keeps them in LDS, derives the per-tensor activation amax max_j a_j / s_j redundantly, then quantises its weight row.
+// Block 0 publishes s, 1/s, the activation scale and the amax (calibration harvest reads it back).
+__global__ __launch_bounds__(256) void sq_prep_fused_kernel(const float *__restrict__ pieces, const float *__restrict__ w_colmax,
+                                                            const float *__restrict__ weight, int Cin, int ntaps, TapMasks tm,
+                                                            float alpha, float qmax_w, const float *__restrict__ static_amax_w,
+                                                            float static_amax_x, float qmax_a, float *__restrict__ s_out,
+                                                            float *__restrict__ r_out, float *__restrict__ amax_x_acc,
+                                                            float *__restrict__ scal, int8_t *__restrict__ wq,
+                                                            float *__restrict__ out_mul, float *__restrict__ amax_w_out) {
+    extern __shared__ float s_lds[];        // [K]
+    __shared__ float sh[16];
+    const int K = Cin * ntaps;
+    const int oc = blockIdx.x;
+    const float eps = 1.0f / (float)(1 << 24);
+    float t = 0.f;
+    for (int j = threadIdx.x; j < K; j += 256) {
+        const int tap = j / Cin, c = j - tap * Cin;
+        const unsigned mask = tm.m[tap];
+        float a = 0.f;
+#pragma unroll
+        for (int p = 0; p < 16; ++p)
+            if (mask & (1u << p)) a = fmaxf(a, pieces[p * Cin + c]);
+        float s = 1.f;
+        if (alpha >= 0.f) {
+            const float w = w_colmax[j];
+            if (alpha == 0.5f) s = __fdiv_rn(sqrtf(a), sqrtf(w));
+            else s = __fdiv_rn(powf(a, alpha), powf(w, 1.f - alpha));
+            if (s == 0.f) s = 1.f;
+        }
+        s_lds[j] = s;
+        if (oc == 0) {
+            s_out[j] = s;
+            r_out[j] = __fdiv_rn(1.0f, s);
+        }
+        t = fmaxf(t, fabsf(__fdiv_rn(a, s)));
+    }
+    const float amax_dyn = block_max_1024(t, sh);       // also orders the s_lds writes before the reads below
+    const float amax_x = static_amax_x > 0.f ? static_amax_x : amax_dyn;
+    float sx = __fdiv_rn(qmax_a, amax_x), dvx = sx;
+    if (amax_x <= eps) { sx = 0.f; dvx = 1.f; }
+    const float inv_sx = __fdiv_rn(1.0f, dvx);
+    if (oc == 0 && threadIdx.x == 0) {
+        scal[0] = sx; scal[1] = amax_x; scal[2] = inv_sx; scal[3] = static_amax_x > 0.f ? 1.f : 0.f;
+        if (amax_dyn > 0.f && amax_dyn > *amax_x_acc) aq3d_atomic_max_pos(amax_x_acc, amax_dyn);
+    }
+    const float *wrow = weight + (size_t)oc * K;
+    float mx = 0.f;
+    for (int j = threadIdx.x; j < K; j += 256) mx = fmaxf(mx, fabsf(__fmul_rn(wrow[j], s_lds[j])));
+    float amax = block_max_1024(mx, sh);
+    if (threadIdx.x == 0) amax_w_out[oc] = amax;
+    if (static_amax_w) amax = static_amax_w[oc];
+    float sw = __fdiv_rn(qmax_w, amax), dv = sw;
+    if (amax <= eps) { sw = 0.f; dv = 1.f; }
+    for (int j = threadIdx.x; j < K; j += 256) {
+        float q = rintf(__fmul_rn(__fmul_rn(wrow[j], s_lds[j]), sw));
+        q = fminf(fmaxf(q, -qmax_w - 1.f), qmax_w);
+        wq[(size_t)oc * K + j] = (int8_t)(int)q;
+    }
+    if (threadIdx.x == 0) out_mul[oc] = __fmul_rn(inv_sx, __fdiv_rn(1.0f, dv));
+}
+
 extern "C" int aq3d_sq_prep(const float *pieces, const float *weight, const float *w_colmax,
                             const aq3d_conv2d_geom *g, float alpha, int32_t w_bits, int32_t a_bits,
                             float static_amax_x, const float *static_amax_w, float *amax_x_acc, void *params,
@@ -244,6 +307,15 @@ extern "C" int aq3d_sq_prep(const float *pieces, const float *weight, const floa
     int8_t *wq = (int8_t *)(base + l.wq);
     const int ntaps = g->ksize * g->ksize, K = g->Cin * ntaps;
     const float qa = (float)((1 << (a_bits - 1)) - 1), qw = (float)((1 << (w_bits - 1)) - 1);
+    // measured: the fused single launch is SLOWER than the two small ones (13.6-28 us vs 14-16 us per layer; every block
+    // redoes 16 x K piece reads), so it stays an experiment
+    static const bool fused = getenv("AQ3D_SQ_PREP_FUSED") != nullptr;
+    if (fused && (size_t)K * 4 <= 60 * 1024) {
+        hipLaunchKernelGGL(sq_prep_fused_kernel, dim3(g->Cout), dim3(256), (size_t)K * 4, stream, pieces, w_colmax, weight, g->Cin,
+                           ntaps, tm, alpha, qw, static_amax_w, static_amax_x, qa, s, r, amax_x_acc, scal, wq, mul, amaxw);
+        AQ3D_CHECK_LAUNCH("aq3d_sq_prep");
+        return AQ3D_OK;
+    }
     hipLaunchKernelGGL(sq_scales_kernel, dim3(aq3d_div_up(K, 256)), dim3(256), 0, stream, pieces, w_colmax, g->Cin, ntaps, tm,
                        alpha, s, r, amax_x_acc);
     hipLaunchKernelGGL(sq_weights_kernel, dim3(g->Cout), dim3(256), 0, stream, weight, s, K, qw, static_amax_w, amax_x_acc,
