@@ -35,6 +35,7 @@ struct ConvArgs {
     float *pieces_out;      // optional [16][pieces_ld] abs-max accumulator of the output image
     int pieces_ld;
     long long *stamps;      // diagnostic builds only (AQ3D_I8_STAMP)
+    int pieces_mode;        // 0: 16 exact classes; 1: the four interior classes merged (all consumers have stride 1)
 };
 
 __device__ __forceinline__ int piece_cls(int i, int n) { return i == 0 ? 0 : (i == n - 1 ? 1 : 2 + (i & 1)); }
@@ -194,6 +195,18 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvArgs a) {
     mma_step((nk - 1) & 1);
 
     // epilogue: lane holds oc = base + 4g .. 4g+3 for pixel column l15
+    float mint[4] = {0.f, 0.f, 0.f, 0.f};
+    int pcls[TJ];                           // piece class of this lane's TJ pixels; -1 = interior in merged mode
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        pcls[j] = 0;
+        if (a.pieces_out) {
+            const int p = pix0 + wn * (BN / 2) + j * 16 + l15;
+            const int ho = p / a.Wo, wo = p - ho * a.Wo;
+            pcls[j] = (a.pieces_mode == 1 && ho > 0 && ho < a.Ho - 1 && wo > 0 && wo < a.Wo - 1)
+                          ? -1 : piece_cls(ho, a.Ho) * 4 + piece_cls(wo, a.Wo);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int oc = oc0 + wm * (BM / 2) + i * 16 + 4 * g;
@@ -220,10 +233,28 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvArgs a) {
             }
             *reinterpret_cast<f32x4 *>(a.y + (size_t)p * a.out_ld + a.out_coff + oc) = v;
             if (a.pieces_out) {
-                const int ho = p / a.Wo;
-                const int pc = piece_cls(ho, a.Ho) * 4 + piece_cls(p - ho * a.Wo, a.Wo);
+                if (pcls[j] < 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) atomicMax(&pm[pc * BM + (oc - oc0) + r], __float_as_uint(fabsf(v[r])));
+                    for (int r = 0; r < 4; ++r) mint[r] = fmaxf(mint[r], fabsf(v[r]));      // interior: reduced in registers below
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicMax(&pm[pcls[j] * BM + (oc - oc0) + r], __float_as_uint(fabsf(v[r])));
+                }
+            }
+        }
+        if (a.pieces_out && a.pieces_mode == 1) {
+            // interior pixels (98 % of the image): max over this wave's pixel columns with 4 xor-shuffles per value, then ONE
+            // LDS atomic per (wave, channel) instead of one per (pixel, channel) — same-address LDS atomics from the 16 pixel
+            // lanes were what made the fused epilogue slower than a separate pass
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float m = mint[r];
+                m = fmaxf(m, __shfl_xor(m, 1, 64));
+                m = fmaxf(m, __shfl_xor(m, 2, 64));
+                m = fmaxf(m, __shfl_xor(m, 4, 64));
+                m = fmaxf(m, __shfl_xor(m, 8, 64));
+                if (l15 == 0 && m > 0.f) atomicMax(&pm[10 * BM + (oc - oc0) + r], __float_as_uint(m));
+                mint[r] = 0.f;
             }
         }
     }
@@ -234,7 +265,10 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvArgs a) {
             const int pc = i / BM, oc = oc0 + i % BM;
             if (v != 0u && oc < a.Cout) {
                 unsigned int *dst = reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc * a.pieces_ld + a.out_coff + oc;
-                if (v > *dst) atomicMax(dst, v);
+                // mode 1: the merged interior maximum lives in class (2,2) alone — the other three interior slots stay zero and
+                // every stride-1 consumer takes the max over all four; fire-and-forget atomic (no dependent read in the tail)
+                if (a.pieces_mode == 1) atomicMax(dst, v);
+                else if (v > *dst) atomicMax(dst, v);
             }
         }
     }
@@ -768,6 +802,7 @@ static int fill_args(ConvArgs *a, const float *x, const aq3d_conv2d_geom *g, con
     a->pieces_out = nullptr;
     a->pieces_ld = 0;
     a->stamps = nullptr;
+    a->pieces_mode = 0;
     a->w = nullptr;
     a->rows_total = g->Cout;
     return AQ3D_OK;
@@ -775,7 +810,7 @@ static int fill_args(ConvArgs *a, const float *x, const aq3d_conv2d_geom *g, con
 
 extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_conv2d_geom *g, const float *bias,
                               const float *post_scale, const float *post_shift, float *y, float *pieces_out,
-                              int32_t pieces_ld, void *stream_) {
+                              int32_t pieces_ld, int32_t pieces_mode, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     ConvArgs a;
     int rc = fill_args(&a, x, g, bias, post_scale, post_shift, y, "aq3d_conv2d_i8");
@@ -783,6 +818,8 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
     AQ3D_REQUIRE(!pieces_out || (pieces_ld >= g->out_coff + g->Cout && g->Ho >= 3 && g->Wo >= 3), "aq3d_conv2d_i8: bad pieces_out layout");
     a.pieces_out = pieces_out;
     a.pieces_ld = pieces_ld;
+    a.pieces_mode = pieces_mode;
+    AQ3D_REQUIRE(pieces_mode == 0 || pieces_mode == 1, "aq3d_conv2d_i8: pieces_mode=%d", pieces_mode);
     AQ3D_REQUIRE(params, "aq3d_conv2d_i8: null params");
     AQ3D_REQUIRE((g->Cin & 63) == 0, "aq3d_conv2d_i8: Cin=%d must be a multiple of 64", g->Cin);
     AQ3D_REQUIRE((g->Cout & 3) == 0 && (g->out_ld & 3) == 0 && (g->out_coff & 3) == 0, "aq3d_conv2d_i8: Cout/out_ld/out_coff must be multiples of 4");

@@ -415,7 +415,11 @@ class Engine:
         self._pieces = {}
         self._producers = {}
         import os
-        self.fuse_pieces = os.environ.get("AQ3D_FUSE_PIECES", "0") != "0"   # measured slower than the standalone pass (epilogue atomics)
+        # piece maxima of a conv's input produced in the epilogue of the conv(s) that wrote it: "1" (default) = int8 producers
+        # feeding stride-1 consumers (register-reduced interior maximum, pieces_mode 1); "all" = every producer, exact 16
+        # classes (per-element LDS atomics: measured slower than the standalone pass); "0" = always the standalone pass
+        self.fuse_pieces = os.environ.get("AQ3D_FUSE_PIECES", "1")
+        self._pieces_mode = {}
 
         def compile_conv2d(mod, path, x, xH, xW, x_ld, pad_extra, bn, relu, out=None, out_ld=None, out_coff=0):
             """mod: nn.Conv2d | SQConv2d | QuantConv2d | nn.ConvTranspose2d. x: [B, xH, xW, x_ld] buffer."""
@@ -451,15 +455,23 @@ class Engine:
                     rec["w_colmax"] = rec["weight"].abs().max(dim=0)[0].contiguous()
                     rec["alpha"] = mod.scaling_factor
                     pkey = (x.data_ptr(), x_ld, cin, xH, xW)      # one abs-max pass per input tensor, shared by its consumers
+                    if pkey in self._pieces and self._pieces_mode.get(pkey, 0) == 1 and s != 1:
+                        pkey = pkey + ("exact",)                  # merged-interior maxima do not serve a strided consumer
                     rec["pieces_owner"] = pkey not in self._pieces
                     if rec["pieces_owner"]:
                         self._pieces[pkey] = self.arena.alloc(16 * cin)
                         # if the tensor is written by conv kernels, they produce its piece maxima in their epilogues
                         prods = self._producers.get(x.data_ptr(), [])
                         covered = sum(p_["geom"].Cout for p_ in prods)
-                        if prods and covered >= cin and x_ld == cin and xH >= 3 and xW >= 3 and self.fuse_pieces:
+                        fusable = prods and covered >= cin and x_ld == cin and xH >= 3 and xW >= 3 and len(pkey) == 5
+                        if fusable and self.fuse_pieces == "all":
                             for p_ in prods:
-                                p_["pieces_out"] = (self._pieces[pkey], cin)
+                                p_["pieces_out"] = (self._pieces[pkey], cin, 0)
+                            rec["pieces_owner"] = False
+                        elif fusable and self.fuse_pieces == "1" and s == 1 and all(p_["kind"] == "i8" for p_ in prods):
+                            for p_ in prods:
+                                p_["pieces_out"] = (self._pieces[pkey], cin, 1)
+                            self._pieces_mode[pkey] = 1
                             rec["pieces_owner"] = False
                     rec["pieces"] = self._pieces[pkey]
                     rec["params"] = torch.empty((ops.sq_param_bytes(cin, g.Cout, k),), dtype=torch.uint8, device=dev)
@@ -712,7 +724,7 @@ class Engine:
             with _Timed(self, "conv2d_i8"):
                 for b in range(B):
                     ops.conv2d_i8(x[b], rec["params"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b],
-                                  pieces_out=po)
+                                  pieces_out=po, pieces_mode=rec["pieces_out"][2] if po is not None else 0)
         else:
             cal = rec.get("calib")
             if cal is not None:

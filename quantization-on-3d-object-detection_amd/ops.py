@@ -251,13 +251,13 @@ def sq_prep(pieces, weight_k, w_colmax, g, alpha, params=None, w_bits=8, a_bits=
     return params
 
 
-def conv2d_i8(x, params, g, bias=None, post_scale=None, post_shift=None, out=None, pieces_out=None):
+def conv2d_i8(x, params, g, bias=None, post_scale=None, post_shift=None, out=None, pieces_out=None, pieces_mode=0):
     """pieces_out: optional f32 [16, ld] accumulator that receives the piece abs-max of the OUTPUT (fused, caller-zeroed)."""
     L = _lib.load()
     Ho, Wo = out_hw(g)
     y = out if out is not None else torch.empty((Ho, Wo, g.out_ld), dtype=f32, device=x.device)
     check(L.aq3d_conv2d_i8(_p(x), _p(params), ctypes.byref(g), _p(bias), _p(post_scale), _p(post_shift), _p(y),
-                           _p(pieces_out), 0 if pieces_out is None else pieces_out.shape[1], _stream()), "aq3d_conv2d_i8")
+                           _p(pieces_out), 0 if pieces_out is None else pieces_out.shape[1], int(pieces_mode), _stream()), "aq3d_conv2d_i8")
     return y
 
 

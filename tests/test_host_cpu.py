@@ -39,7 +39,7 @@ def test_argument_validation_returns_codes_not_exit():
     with pytest.raises(lib.Aq3dError):
         lib.check(rc, "aq3d_spconv")
     g = lib.Conv2dGeom()
-    rc = L.aq3d_conv2d_i8(None, None, ctypes.byref(g), None, None, None, None, None, 0, None)
+    rc = L.aq3d_conv2d_i8(None, None, ctypes.byref(g), None, None, None, None, None, 0, 0, None)
     assert rc < 0
 
 
