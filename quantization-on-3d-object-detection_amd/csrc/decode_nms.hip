@@ -81,8 +81,24 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
     auto key_of = [&](int i) -> unsigned int {
         return cache_keys ? keys_s[i] : __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
     };
-    if (cache_keys)
-        for (int i = threadIdx.x; i < L; i += blockDim.x) keys_s[i] = __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
+    if (cache_keys) {
+        // strided column read (one float per pixel row): 8 independent loads in flight per thread — with one load per
+        // iteration this loop alone was ~35 dependent L2 round trips (the kernel's 76 us were mostly spent here)
+        const int nth = blockDim.x;
+        for (int base = threadIdx.x; base < L; base += 8 * nth) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * nth;
+                v[u] = i < L ? col[(size_t)i * hm_ld] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * nth;
+                if (i < L) keys_s[i] = __float_as_uint(sigmoidf_dev(v[u]));
+            }
+        }
+    }
 
     // 4-pass MSB radix select on the 32-bit score keys: find T = Keff-th largest key
     if (threadIdx.x == 0) { s_prefix = 0u; s_remaining = Keff; }
@@ -479,11 +495,18 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(const u64 *__restrict__ 
     for (int b = 0; b < nb; ++b) {
         const int row = b * 64 + lane;
         const u64 diag = (row < n) ? msrc[(size_t)row * col_blocks + b] : 0ull;
-        u64 cur = __shfl(remv, b, 64);
+        // the greedy chain is wave-uniform: keep it on the scalar unit (v_readlane + 64-bit SALU ops) instead of 64-wide
+        // shuffles and VALU bit ops that every lane repeats
+        auto bcast = [&](u64 v, int src) -> u64 {
+            const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, src);
+            const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+            return ((u64)hi << 32) | lo;
+        };
+        u64 cur = bcast(remv, b);
         u64 kept = 0ull;
         const int lim = min(64, n - b * 64);
         for (int t = 0; t < lim; ++t) {
-            const u64 d = __shfl(diag, t, 64);
+            const u64 d = bcast(diag, t);
             const bool take = !((cur >> t) & 1ull);
             if (take) { kept |= 1ull << t; cur |= d; }
         }
