@@ -11,6 +11,7 @@
 // (one blocking D2H per head per frame); here one wave sweeps it on device, 64 boxes per step. torch.topk's order
 // among equal scores is unspecified; we fix it to (score desc, flat index asc) and the oracle does the same.
 #include "common.h"
+#include <stdlib.h>
 
 typedef unsigned long long u64;
 
@@ -63,7 +64,7 @@ __device__ __forceinline__ float sigmoidf_dev(float x) { return __fdiv_rn(1.0f, 
 // slots beyond the number of pixels hold 0.
 __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__restrict__ hm, int hm_ld, int L_static,
                                                               const int *__restrict__ count, int K, int Kpad,
-                                                              int cache_keys, u64 *__restrict__ out) {
+                                                              int cache_keys, float score_thresh, u64 *__restrict__ out) {
     int L = L_static;            // dense map: H*W pixels; sparse head: the live rows (device count, capped by L_static)
     if (count) { L = *count; if (L > L_static) L = L_static; if (L < 0) L = 0; }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -77,13 +78,58 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
     __shared__ unsigned int tie_idx[TIE_CAP];
     const int cls = blockIdx.x;
     const float *col = hm + cls;
-    const int Keff = K < L ? K : L;
     auto key_of = [&](int i) -> unsigned int {
         return cache_keys ? keys_s[i] : __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
     };
-    if (cache_keys) {
-        // strided column read (one float per pixel row): 8 independent loads in flight per thread — with one load per
-        // iteration this loop alone was ~35 dependent L2 round trips (the kernel's 76 us were mostly spent here)
+    // Pre-filter: a candidate whose score is not above score_thresh is masked by the decode stage whatever its rank, so
+    // the top-K only has to be found among the scores above it (if fewer than K exist, the missing ones would be masked
+    // anyway). An ORDER-PRESERVING compaction (each wave owns a contiguous pixel range; counts, a 16-wave prefix, then
+    // ballot-ranked writes) shrinks the radix-select domain from H*W to the few thousand live peaks and keeps every tie
+    // rule (smaller pixel index first) intact. Falls back to the full map when more than FCAP scores pass.
+    constexpr int FPER = 36, FCAP = 16384;
+    unsigned int *idx_s = keys_s + FCAP;                   // filtered mode: [FCAP] original pixel indices
+    __shared__ int s_wcnt[16], s_filtered;
+    const bool try_filter = cache_keys && score_thresh >= 0.f && L <= FPER * 1024 && blockDim.x == 1024;
+    if (threadIdx.x == 0) s_filtered = 0;
+    if (try_filter) {
+        const unsigned int tkey = __float_as_uint(score_thresh);
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int chunk = (((L + 15) >> 4) + 63) & ~63;     // pixels per wave, multiple of 64
+        const int beg = w * chunk, end = min(L, beg + chunk);
+        unsigned int kv[FPER];
+        int cnt = 0;
+#pragma unroll
+        for (int it = 0; it < FPER; ++it) {
+            const int i = beg + it * 64 + lane;
+            kv[it] = (it * 64 < chunk && i < end) ? __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld])) : 0u;
+            cnt += (int)__popcll(__ballot(kv[it] > tkey));
+        }
+        if (lane == 0) s_wcnt[w] = cnt;
+        __syncthreads();
+        int base = 0, total = 0;
+        for (int q = 0; q < 16; ++q) { base += q < w ? s_wcnt[q] : 0; total += s_wcnt[q]; }
+        if (total <= FCAP) {
+#pragma unroll
+            for (int it = 0; it < FPER; ++it) {
+                const bool pass_ = kv[it] > tkey;
+                const u64 m = __ballot(pass_);
+                if (pass_) {
+                    const int pos = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+                    keys_s[pos] = kv[it];
+                    idx_s[pos] = (unsigned int)(beg + it * 64 + lane);
+                }
+                base += (int)__popcll(m);
+            }
+            if (threadIdx.x == 0) s_filtered = 1;
+            L = total;
+        }
+        __syncthreads();
+    }
+    const bool filtered = try_filter && s_filtered;
+    const int Keff = K < L ? K : L;
+    auto orig = [&](int i) -> unsigned int { return filtered ? idx_s[i] : (unsigned int)i; };
+    if (cache_keys && !filtered) {
+        // strided column read (one float per pixel row): 8 independent loads in flight per thread
         const int nth = blockDim.x;
         for (int base = threadIdx.x; base < L; base += 8 * nth) {
             float v[8];
@@ -170,10 +216,10 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
         const unsigned int key = key_of(i);
         if (key > T) {
             int pos = atomicAdd(&s_fill, 1);
-            sel[pos] = ((u64)key << 32) | (u64)(0xffffffffu - (unsigned int)i);
+            sel[pos] = ((u64)key << 32) | (u64)(0xffffffffu - orig(i));
         } else if (key == T) {
             int pos = atomicAdd(&s_ties, 1);
-            if (pos < TIE_CAP) tie_idx[pos] = (unsigned int)i;
+            if (pos < TIE_CAP) tie_idx[pos] = orig(i);
         }
     }
     __syncthreads();
@@ -195,7 +241,7 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
             if (i < L) f = (key_of(i) == T) ? 1 : 0;
             int tot;
             int pos = block_scan_excl_1024(f, sh, &tot);
-            if (f && taken + pos < need_ties) sel[gt + taken + pos] = ((u64)T << 32) | (u64)(0xffffffffu - (unsigned int)i);
+            if (f && taken + pos < need_ties) sel[gt + taken + pos] = ((u64)T << 32) | (u64)(0xffffffffu - orig(i));
             taken += tot;
         }
     }
@@ -300,12 +346,15 @@ extern "C" int aq3d_center_decode(const float *hm, const float *center, const fl
     const int Kpad = next_pow2(K);
     u64 *cand = (u64 *)workspace;
     size_t lds1 = (size_t)Kpad * 8 + 256 * 4 + 16 * 4;
-    const int cache_keys = (lds1 + (size_t)L * 4 <= 150 * 1024) ? 1 : 0;   // one workgroup may use up to 160 KiB of LDS
-    if (cache_keys) lds1 += (size_t)L * 4;
+    static const bool no_filter = getenv("AQ3D_TOPK_NOFILTER") != nullptr;
+    // key cache [L] — or, in the pre-filtered mode, keys + pixel indices of up to 16384 candidates (2 x 64 KiB)
+    const size_t key_bytes = (size_t)L * 4 > 131072 ? (size_t)L * 4 : 131072;
+    const int cache_keys = (lds1 + key_bytes <= 150 * 1024) ? 1 : 0;   // one workgroup may use up to 160 KiB of LDS
+    if (cache_keys) lds1 += key_bytes;
     if (lds1 > 64 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(topk_per_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     hipLaunchKernelGGL(topk_per_class_kernel, dim3(cfg->num_classes), dim3(1024), lds1, stream, hm, cfg->hm_ld, L, (const int *)nullptr,
-                       K, Kpad, cache_keys, cand);
+                       K, Kpad, cache_keys, no_filter ? -1.f : cfg->score_thresh, cand);
     const int ncand = cfg->num_classes * K;
     const int Npad = next_pow2(ncand);
     DecodeParams q;
@@ -335,12 +384,13 @@ extern "C" int aq3d_voxel_decode(const float *hm, const float *center, const flo
     const int K = cfg->K, Kpad = next_pow2(K);
     u64 *cand = (u64 *)workspace;
     size_t lds1 = (size_t)Kpad * 8 + 256 * 4 + 16 * 4;
-    const int cache_keys = (lds1 + (size_t)cap * 4 <= 150 * 1024) ? 1 : 0;
-    if (cache_keys) lds1 += (size_t)cap * 4;
+    const size_t key_bytes = (size_t)cap * 4 > 131072 ? (size_t)cap * 4 : 131072;
+    const int cache_keys = (lds1 + key_bytes <= 150 * 1024) ? 1 : 0;
+    if (cache_keys) lds1 += key_bytes;
     if (lds1 > 64 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(topk_per_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     hipLaunchKernelGGL(topk_per_class_kernel, dim3(cfg->num_classes), dim3(1024), lds1, stream, hm, cfg->hm_ld, cap, count, K, Kpad,
-                       cache_keys, cand);
+                       cache_keys, cfg->score_thresh, cand);
     const int ncand = cfg->num_classes * K, Npad = next_pow2(ncand);
     DecodeParams q;
     q.c = *cfg; q.center = center; q.center_z = center_z; q.dim = dim; q.rot = rot; q.vel = vel; q.coords = coords;
