@@ -214,6 +214,19 @@ int aq3d_sq_prep(const float *pieces, const float *weight, const float *w_colmax
                  const aq3d_conv2d_geom *g, float alpha, int32_t w_bits, int32_t a_bits,
                  float static_amax_x, const float *static_amax_w, float *amax_x_acc, void *params, void *stream);
 
+/* One layer of a grouped aq3d_sq_prep launch (same arguments; the layers must share H, W, Cin, ksize, stride, pad). */
+typedef struct aq3d_sq_prep_problem {
+    const float *pieces, *weight, *w_colmax;
+    const aq3d_conv2d_geom *geom;
+    float alpha, static_amax_x;
+    const float *static_amax_w;
+    float *amax_x_acc;
+    void *params;
+} aq3d_sq_prep_problem;
+
+/* aq3d_sq_prep for up to 8 layers in two launches instead of 2 n (the branches of one CenterHead SeparateHead). */
+int aq3d_sq_prep_group(const aq3d_sq_prep_problem *problems, int32_t n, int32_t w_bits, int32_t a_bits, void *stream);
+
 /* y = epilogue( int32 GEMM of quantised im2col(x) with quantised weights ) — SQConv2d.forward.
  *   epilogue: v = acc * out_mul[o] + bias[o]; y = v * post_scale[o] + post_shift[o]; relu.
  *   pieces_out (may be NULL): f32 [16, pieces_ld] piece abs-max accumulator of the OUTPUT tensor (same definition as
@@ -224,6 +237,23 @@ int aq3d_sq_prep(const float *pieces, const float *weight, const float *w_colmax
 int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_conv2d_geom *g,
                    const float *bias, const float *post_scale, const float *post_shift,
                    float *y, float *pieces_out, int32_t pieces_ld, int32_t pieces_mode, void *stream);
+
+/* One convolution of a grouped launch (the arguments of aq3d_conv2d_i8 / aq3d_conv2d_f32). */
+typedef struct aq3d_conv2d_problem {
+    const float *x;
+    const void *weight_or_params;      /* i8: the aq3d_sq_prep parameter block; f32: weight f32 [Cout_total, K] */
+    const aq3d_conv2d_geom *geom;
+    const float *bias, *post_scale, *post_shift;
+    float *y;
+    float *pieces_out;
+    int32_t pieces_ld, pieces_mode;
+} aq3d_conv2d_problem;
+
+/* Up to 8 independent convolutions of one launch class (same H, W, Cin, ksize, stride, pad; Cout on the same side of 128
+ * for i8, same row class for f32) as ONE kernel launch — the per-branch convs of CenterHead's SeparateHead
+ * (pcdet/models/dense_heads/center_head.py:12-46), each too small to fill the chip on its own. */
+int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *problems, int32_t n, void *stream);
+int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *problems, int32_t n, void *stream);
 
 /* fp32 conv / transposed conv (MFMA f32), weight f32 [Cout_total, K] with K ordered (kh, kw, c);
  * for deconv = d the weight rows are ordered (i, j, o): row = (i*d + j)*Cout + o. */

@@ -38,6 +38,13 @@ struct ConvArgs {
     int pieces_mode;        // 0: 16 exact classes; 1: the four interior classes merged (all consumers have stride 1)
 };
 
+// Up to 8 independent convolutions of one launch class in a single grid (blockIdx.z = problem): the head's per-branch convs
+// are each too small to fill the chip and were a third of the dense launches.
+#define AQ3D_MAX_GROUP 8
+struct ConvGroup {
+    ConvArgs p[AQ3D_MAX_GROUP];
+};
+
 __device__ __forceinline__ int piece_cls(int i, int n) { return i == 0 ? 0 : (i == n - 1 ? 1 : 2 + (i & 1)); }
 
 // exact fp32 division x / s given r = RN(1/s): one Newton correction on the quotient (Markstein)
@@ -74,7 +81,9 @@ __device__ __forceinline__ int quant_pack4(f32x4 v, f32x4 s, f32x4 r, float sxv)
 
 // ------------------------------------------------------------------ int8 SmoothQuant conv
 template <int TI, int TJ>
-__global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvGroup grp) {
+    const ConvArgs a = grp.p[blockIdx.z];
+    if ((int)blockIdx.y * 32 * TI >= a.Cout) return;      // a problem with fewer channel blocks than the widest of its group
     constexpr int BM = 32 * TI;   // output channels per workgroup
     constexpr int BN = 32 * TJ;   // pixels per workgroup
     constexpr int LD = 80;        // bytes per LDS row: 64 + 16 pad (conflict-free ds_read_b128 of 16 rows)
@@ -641,7 +650,9 @@ __global__ __launch_bounds__(256) void conv2d_i8_direct_kernel(ConvArgs a) {
 // ------------------------------------------------------------------ fp32 conv / transposed conv
 // WM x WN waves; wave tile (TI*16) rows x (TJ*16) pixels; K step = 16 input channels of one tap.
 template <int WM, int WN, int TI, int TJ>
-__global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvGroup grp) {
+    const ConvArgs a = grp.p[blockIdx.z];
+    if ((int)blockIdx.y * WM * TI * 16 >= a.rows_total) return;
     constexpr int BM = WM * TI * 16;
     constexpr int BN = WN * TJ * 16;
     constexpr int LD = 20;  // floats per LDS row: 16 + 4 pad
@@ -808,35 +819,60 @@ static int fill_args(ConvArgs *a, const float *x, const aq3d_conv2d_geom *g, con
     return AQ3D_OK;
 }
 
-extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_conv2d_geom *g, const float *bias,
-                              const float *post_scale, const float *post_shift, float *y, float *pieces_out,
-                              int32_t pieces_ld, int32_t pieces_mode, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    ConvArgs a;
-    int rc = fill_args(&a, x, g, bias, post_scale, post_shift, y, "aq3d_conv2d_i8");
+// ---- host side: per-problem argument preparation, then one launch per group of same-class problems
+static int prep_i8(ConvArgs *a, const aq3d_conv2d_problem *q) {
+    const aq3d_conv2d_geom *g = q->geom;
+    int rc = fill_args(a, q->x, g, q->bias, q->post_scale, q->post_shift, q->y, "aq3d_conv2d_i8");
     if (rc != AQ3D_OK) return rc;
-    AQ3D_REQUIRE(!pieces_out || (pieces_ld >= g->out_coff + g->Cout && g->Ho >= 3 && g->Wo >= 3), "aq3d_conv2d_i8: bad pieces_out layout");
-    a.pieces_out = pieces_out;
-    a.pieces_ld = pieces_ld;
-    a.pieces_mode = pieces_mode;
-    AQ3D_REQUIRE(pieces_mode == 0 || pieces_mode == 1, "aq3d_conv2d_i8: pieces_mode=%d", pieces_mode);
-    AQ3D_REQUIRE(params, "aq3d_conv2d_i8: null params");
+    AQ3D_REQUIRE(!q->pieces_out || (q->pieces_ld >= g->out_coff + g->Cout && g->Ho >= 3 && g->Wo >= 3), "aq3d_conv2d_i8: bad pieces_out layout");
+    a->pieces_out = q->pieces_out;
+    a->pieces_ld = q->pieces_ld;
+    a->pieces_mode = q->pieces_mode;
+    AQ3D_REQUIRE(q->pieces_mode == 0 || q->pieces_mode == 1, "aq3d_conv2d_i8: pieces_mode=%d", q->pieces_mode);
+    AQ3D_REQUIRE(q->weight_or_params, "aq3d_conv2d_i8: null params");
     AQ3D_REQUIRE((g->Cin & 63) == 0, "aq3d_conv2d_i8: Cin=%d must be a multiple of 64", g->Cin);
     AQ3D_REQUIRE((g->Cout & 3) == 0 && (g->out_ld & 3) == 0 && (g->out_coff & 3) == 0, "aq3d_conv2d_i8: Cout/out_ld/out_coff must be multiples of 4");
     AQ3D_REQUIRE(g->deconv == 0, "aq3d_conv2d_i8: deconv unsupported");
     AQ3D_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->ksize) / g->stride + 1 && g->Wo == (g->W + 2 * g->pad - g->ksize) / g->stride + 1,
                  "aq3d_conv2d_i8: Ho/Wo inconsistent with geometry");
     const SqLayout l = sq_layout(g->Cin, g->Cout, g->ksize);
-    const char *base = (const char *)params;
-    a.s = (const float *)(base + l.s);
-    a.rinv = (const float *)(base + l.r);
-    a.out_mul = (const float *)(base + l.mul);
-    a.scal = (const float *)(base + l.scal);
-    a.w = base + l.wq;
+    const char *base = (const char *)q->weight_or_params;
+    a->s = (const float *)(base + l.s);
+    a->rinv = (const float *)(base + l.r);
+    a->out_mul = (const float *)(base + l.mul);
+    a->scal = (const float *)(base + l.scal);
+    a->w = base + l.wq;
+    return AQ3D_OK;
+}
+
+static bool same_class(const aq3d_conv2d_geom *a, const aq3d_conv2d_geom *b) {
+    return a->H == b->H && a->W == b->W && a->Cin == b->Cin && a->ksize == b->ksize && a->stride == b->stride && a->pad == b->pad &&
+           a->Ho == b->Ho && a->Wo == b->Wo && a->deconv == b->deconv;
+}
+
+extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(probs && n >= 1 && n <= AQ3D_MAX_GROUP, "aq3d_conv2d_i8_group: n=%d not in 1..%d", n, AQ3D_MAX_GROUP);
+    ConvGroup grp;
+    int max_cout = 0;
+    bool any_pieces = false;
+    for (int i = 0; i < n; ++i) {
+        AQ3D_REQUIRE(probs[i].geom, "aq3d_conv2d_i8_group: null geometry");
+        int rc = prep_i8(&grp.p[i], &probs[i]);
+        if (rc != AQ3D_OK) return rc;
+        AQ3D_REQUIRE(same_class(probs[0].geom, probs[i].geom) && (probs[0].geom->Cout >= 128) == (probs[i].geom->Cout >= 128),
+                     "aq3d_conv2d_i8_group: problem %d is not of the launch class of problem 0", i);
+        max_cout = probs[i].geom->Cout > max_cout ? probs[i].geom->Cout : max_cout;
+        any_pieces |= probs[i].pieces_out != nullptr;
+    }
+    for (int i = n; i < AQ3D_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
+    const aq3d_conv2d_geom *g = probs[0].geom;
+    ConvArgs &a = grp.p[0];
+    const float *pieces_out = any_pieces ? (const float *)1 : nullptr;
     const int L = g->Ho * g->Wo;
     static const bool no_halo = getenv("AQ3D_I8_HALO") == nullptr;      // experiment, off by default: not faster than the generic kernel
     static const bool no_direct = getenv("AQ3D_I8_DIRECT") == nullptr;      // measured slower: per-lane 16-byte loads of 64-byte pixel pieces thrash the TA
-    if (!no_direct && !pieces_out && g->ksize == 3 && g->stride == 1 && g->pad == 1 && (g->Cin & 31) == 0 &&
+    if (n == 1 && !no_direct && !pieces_out && g->ksize == 3 && g->stride == 1 && g->pad == 1 && (g->Cin & 31) == 0 &&
         (int64_t)g->H * g->W * g->in_ld * 4 < (int64_t)0xfffffff0) {
         const int bm = g->Cout >= 128 ? 128 : 64;
         const dim3 grid(aq3d_div_up(g->H, 4) * aq3d_div_up(g->W, 16), aq3d_div_up(g->Cout, bm));
@@ -845,7 +881,7 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
         AQ3D_CHECK_LAUNCH("aq3d_conv2d_i8(direct)");
         return AQ3D_OK;
     }
-    if (!no_halo && !pieces_out && g->ksize == 3 && g->stride == 1 && g->pad == 1 && (g->Cin & 31) == 0) {
+    if (n == 1 && !no_halo && !pieces_out && g->ksize == 3 && g->stride == 1 && g->pad == 1 && (g->Cin & 31) == 0) {
         // halo-staged kernel; tile rows chosen so that there are >= 2 workgroups per CU where the image allows it
         const int bm = g->Cout >= 128 ? 128 : 64;
         const int ocb2 = aq3d_div_up(g->Cout, bm), tw = aq3d_div_up(g->W, 16);
@@ -861,9 +897,9 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
             long long hst[8];
             (void)hipStreamSynchronize(stream);
             (void)hipMemcpy(hst, dev, 64, hipMemcpyDeviceToHost);
-            const double n = (double)(hst[5] ? hst[5] : 1);
+            const double nn = (double)(hst[5] ? hst[5] : 1);
             fprintf(stderr, "[i8 halo %dx%d C%d->%d] per wg cycles: chunk-swap %.0f  quantize %.0f  mma %.0f  barrier %.0f  | loop total %.0f\n",
-                    g->H, g->W, g->Cin, g->Cout, hst[0] / n, hst[1] / n, hst[2] / n, hst[3] / n, hst[4] / n);
+                    g->H, g->W, g->Cin, g->Cout, hst[0] / nn, hst[1] / nn, hst[2] / nn, hst[3] / nn, hst[4] / nn);
             return AQ3D_OK;
         }
         if (bm == 128 && tr == 8) hipLaunchKernelGGL((conv2d_i8_halo_kernel<4, 8, false>), grid, dim3(256), 0, stream, a);
@@ -875,13 +911,13 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
     }
     // pixel-tile width: enough workgroups for >= 2 per CU (the K loop is a latency chain, it needs co-resident partners)
     static const int force_bn = getenv("AQ3D_I8_BN") ? atoi(getenv("AQ3D_I8_BN")) : 0;
-    const int ocb = g->Cout >= 128 ? aq3d_div_up(g->Cout, 128) : aq3d_div_up(g->Cout, 64);
+    const int ocb = max_cout >= 128 ? aq3d_div_up(max_cout, 128) : aq3d_div_up(max_cout, 64);
     int bn = 128;
-    if (aq3d_div_up(L, 128) * ocb < 512) bn = 64;
-    if (aq3d_div_up(L, 64) * ocb < 512) bn = 32;
+    if (aq3d_div_up(L, 128) * ocb * n < 512) bn = 64;
+    if (aq3d_div_up(L, 64) * ocb * n < 512) bn = 32;
     if (force_bn) bn = force_bn;
 #define AQ3D_I8_LAUNCH(TI_, TJ_) \
-    hipLaunchKernelGGL((conv2d_i8_kernel<TI_, TJ_>), dim3(aq3d_div_up(L, 32 * TJ_), ocb), dim3(256), 0, stream, a)
+    hipLaunchKernelGGL((conv2d_i8_kernel<TI_, TJ_>), dim3(aq3d_div_up(L, 32 * TJ_), ocb, n), dim3(256), 0, stream, grp)
     if (g->Cout >= 128) {
         if (bn == 128) AQ3D_I8_LAUNCH(4, 4);
         else if (bn == 64) AQ3D_I8_LAUNCH(4, 2);
@@ -896,38 +932,75 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
     return AQ3D_OK;
 }
 
-extern "C" int aq3d_conv2d_f32(const float *x, const float *weight, const aq3d_conv2d_geom *g, const float *bias,
-                               const float *post_scale, const float *post_shift, float *y, float *pieces_out,
-                               int32_t pieces_ld, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    ConvArgs a;
-    int rc = fill_args(&a, x, g, bias, post_scale, post_shift, y, "aq3d_conv2d_f32");
+extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_conv2d_geom *g, const float *bias,
+                              const float *post_scale, const float *post_shift, float *y, float *pieces_out,
+                              int32_t pieces_ld, int32_t pieces_mode, void *stream_) {
+    AQ3D_REQUIRE(g, "aq3d_conv2d_i8: null argument");
+    aq3d_conv2d_problem q;
+    q.x = x; q.weight_or_params = params; q.geom = g; q.bias = bias; q.post_scale = post_scale; q.post_shift = post_shift;
+    q.y = y; q.pieces_out = pieces_out; q.pieces_ld = pieces_ld; q.pieces_mode = pieces_mode;
+    return aq3d_conv2d_i8_group(&q, 1, stream_);
+}
+
+static int prep_f32(ConvArgs *a, const aq3d_conv2d_problem *q, int *L_out) {
+    const aq3d_conv2d_geom *g = q->geom;
+    int rc = fill_args(a, q->x, g, q->bias, q->post_scale, q->post_shift, q->y, "aq3d_conv2d_f32");
     if (rc != AQ3D_OK) return rc;
-    AQ3D_REQUIRE(!pieces_out || pieces_ld >= g->out_coff + g->Cout, "aq3d_conv2d_f32: bad pieces_out layout");
-    a.pieces_out = pieces_out;
-    a.pieces_ld = pieces_ld;
-    AQ3D_REQUIRE(weight, "aq3d_conv2d_f32: null weight");
+    AQ3D_REQUIRE(!q->pieces_out || q->pieces_ld >= g->out_coff + g->Cout, "aq3d_conv2d_f32: bad pieces_out layout");
+    a->pieces_out = q->pieces_out;
+    a->pieces_ld = q->pieces_ld;
+    AQ3D_REQUIRE(q->weight_or_params, "aq3d_conv2d_f32: null weight");
     AQ3D_REQUIRE((g->Cin & 15) == 0, "aq3d_conv2d_f32: Cin=%d must be a multiple of 16", g->Cin);
-    a.w = weight;
-    int L;
+    a->w = q->weight_or_params;
     if (g->deconv > 0) {
         AQ3D_REQUIRE(g->ksize == 1 && g->stride == 1 && g->pad == 0, "aq3d_conv2d_f32: deconv needs ksize=1 stride=1 pad=0 (kernel == stride == deconv)");
         AQ3D_REQUIRE(g->Ho == g->H && g->Wo == g->W, "aq3d_conv2d_f32: deconv takes Ho=H, Wo=W (the input grid)");
-        a.rows_total = g->deconv * g->deconv * g->Cout;
-        L = g->H * g->W;
+        a->rows_total = g->deconv * g->deconv * g->Cout;
+        *L_out = g->H * g->W;
     } else {
         AQ3D_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->ksize) / g->stride + 1 && g->Wo == (g->W + 2 * g->pad - g->ksize) / g->stride + 1,
                      "aq3d_conv2d_f32: Ho/Wo inconsistent with geometry");
-        L = g->Ho * g->Wo;
+        *L_out = g->Ho * g->Wo;
     }
-    const int rows = a.rows_total;
-    if (rows <= 16) {
-        hipLaunchKernelGGL((conv2d_f32_kernel<1, 4, 1, 2>), dim3(aq3d_div_up(L, 128), 1), dim3(256), 0, stream, a);
-    } else if (rows <= 64 || L < 128 * 150) {
-        hipLaunchKernelGGL((conv2d_f32_kernel<2, 2, 2, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(rows, 64)), dim3(256), 0, stream, a);
+    return AQ3D_OK;
+}
+
+static int f32_class(int rows, int L) { return rows <= 16 ? 0 : ((rows <= 64 || L < 128 * 150) ? 1 : 2); }
+
+extern "C" int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *probs, int32_t n, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(probs && n >= 1 && n <= AQ3D_MAX_GROUP, "aq3d_conv2d_f32_group: n=%d not in 1..%d", n, AQ3D_MAX_GROUP);
+    ConvGroup grp;
+    int L = 0, max_rows = 0, cls = 0;
+    for (int i = 0; i < n; ++i) {
+        AQ3D_REQUIRE(probs[i].geom, "aq3d_conv2d_f32_group: null geometry");
+        int Li = 0;
+        int rc = prep_f32(&grp.p[i], &probs[i], &Li);
+        if (rc != AQ3D_OK) return rc;
+        const int ci = f32_class(grp.p[i].rows_total, Li);
+        if (i == 0) { L = Li; cls = ci; }
+        AQ3D_REQUIRE(same_class(probs[0].geom, probs[i].geom) && ci == cls,
+                     "aq3d_conv2d_f32_group: problem %d is not of the launch class of problem 0", i);
+        max_rows = grp.p[i].rows_total > max_rows ? grp.p[i].rows_total : max_rows;
+    }
+    for (int i = n; i < AQ3D_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
+    if (cls == 0) {
+        hipLaunchKernelGGL((conv2d_f32_kernel<1, 4, 1, 2>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
+    } else if (cls == 1) {
+        hipLaunchKernelGGL((conv2d_f32_kernel<2, 2, 2, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
     } else {
-        hipLaunchKernelGGL((conv2d_f32_kernel<2, 2, 4, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(rows, 128)), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((conv2d_f32_kernel<2, 2, 4, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 128), n), dim3(256), 0, stream, grp);
     }
     AQ3D_CHECK_LAUNCH("aq3d_conv2d_f32");
     return AQ3D_OK;
+}
+
+extern "C" int aq3d_conv2d_f32(const float *x, const float *weight, const aq3d_conv2d_geom *g, const float *bias,
+                               const float *post_scale, const float *post_shift, float *y, float *pieces_out,
+                               int32_t pieces_ld, void *stream_) {
+    AQ3D_REQUIRE(g, "aq3d_conv2d_f32: null argument");
+    aq3d_conv2d_problem q;
+    q.x = x; q.weight_or_params = weight; q.geom = g; q.bias = bias; q.post_scale = post_scale; q.post_shift = post_shift;
+    q.y = y; q.pieces_out = pieces_out; q.pieces_ld = pieces_ld; q.pieces_mode = 0;
+    return aq3d_conv2d_f32_group(&q, 1, stream_);
 }

@@ -157,12 +157,23 @@ __device__ __forceinline__ float block_max_1024(float v, float *sh) {
     return r;
 }
 
+// One SmoothQuant preparation problem (a layer) of a grouped launch; blockIdx.y selects it.
+struct SqOne {
+    const float *pieces, *w_colmax, *weight, *static_amax_w;
+    float *s, *r, *amax_x_acc, *scal, *out_mul, *amax_w_out;
+    int8_t *wq;
+    int Cout;
+    float alpha, static_amax_x;
+};
+#define AQ3D_SQ_MAX_GROUP 8
+struct SqGroup {
+    SqOne p[AQ3D_SQ_MAX_GROUP];
+};
+
 // smoothing scales, one column per thread; the per-tensor activation amax max_j a_j / s_j is accumulated with one atomic
 // per block into a caller-zeroed slot
-__global__ __launch_bounds__(256) void sq_scales_kernel(const float *__restrict__ pieces,
-                                                        const float *__restrict__ w_colmax, int Cin, int ntaps,
-                                                        TapMasks tm, float alpha, float *__restrict__ s_out,
-                                                        float *__restrict__ r_out, float *__restrict__ amax_x_acc) {
+__global__ __launch_bounds__(256) void sq_scales_kernel(SqGroup grp, int Cin, int ntaps, TapMasks tm) {
+    const SqOne q = grp.p[blockIdx.y];
     __shared__ float sh[16];
     const int K = Cin * ntaps;
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -173,52 +184,50 @@ __global__ __launch_bounds__(256) void sq_scales_kernel(const float *__restrict_
         float a = 0.f;
 #pragma unroll
         for (int p = 0; p < 16; ++p)
-            if (mask & (1u << p)) a = fmaxf(a, pieces[p * Cin + c]);
+            if (mask & (1u << p)) a = fmaxf(a, q.pieces[p * Cin + c]);
         float s = 1.f;
-        if (alpha >= 0.f) {
-            const float w = w_colmax[j];
+        if (q.alpha >= 0.f) {
+            const float w = q.w_colmax[j];
             // torch.pow(x, 0.5) takes the sqrt path; other exponents go through powf
-            if (alpha == 0.5f) s = __fdiv_rn(sqrtf(a), sqrtf(w));
-            else s = __fdiv_rn(powf(a, alpha), powf(w, 1.f - alpha));
+            if (q.alpha == 0.5f) s = __fdiv_rn(sqrtf(a), sqrtf(w));
+            else s = __fdiv_rn(powf(a, q.alpha), powf(w, 1.f - q.alpha));
             if (s == 0.f) s = 1.f;
         }
-        s_out[j] = s;
-        r_out[j] = __fdiv_rn(1.0f, s);
+        q.s[j] = s;
+        q.r[j] = __fdiv_rn(1.0f, s);
         t = fabsf(__fdiv_rn(a, s));
     }
     const float m = block_max_1024(t, sh);
-    if (threadIdx.x == 0 && m > 0.f && m > *amax_x_acc) aq3d_atomic_max_pos(amax_x_acc, m);
+    if (threadIdx.x == 0 && m > 0.f && m > *q.amax_x_acc) aq3d_atomic_max_pos(q.amax_x_acc, m);
 }
 
 // one block per output channel: W' = W * s, per-row amax, int8 codes, combined dequant multiplier
-__global__ __launch_bounds__(256) void sq_weights_kernel(const float *__restrict__ weight, const float *__restrict__ s,
-                                                         int K, float qmax_w, const float *__restrict__ static_amax_w,
-                                                         const float *__restrict__ amax_x_acc, float static_amax_x,
-                                                         float qmax_a, float *__restrict__ scal, int8_t *__restrict__ wq,
-                                                         float *__restrict__ out_mul, float *__restrict__ amax_w_out) {
-    __shared__ float sh[16];
+__global__ __launch_bounds__(256) void sq_weights_kernel(SqGroup grp, int K, float qmax_w, float qmax_a) {
+    const SqOne q = grp.p[blockIdx.y];
     const int oc = blockIdx.x;
+    if (oc >= q.Cout) return;
+    __shared__ float sh[16];
     const float eps = 1.0f / (float)(1 << 24);
     // per-tensor activation scale (every block derives it; block 0 publishes it for the conv kernel)
-    const float amax_x = static_amax_x > 0.f ? static_amax_x : *amax_x_acc;
+    const float amax_x = q.static_amax_x > 0.f ? q.static_amax_x : *q.amax_x_acc;
     float sx = __fdiv_rn(qmax_a, amax_x), dvx = sx;
     if (amax_x <= eps) { sx = 0.f; dvx = 1.f; }
     const float inv_sx = __fdiv_rn(1.0f, dvx);
-    if (oc == 0 && threadIdx.x == 0) { scal[0] = sx; scal[1] = amax_x; scal[2] = inv_sx; scal[3] = static_amax_x > 0.f ? 1.f : 0.f; }
-    const float *wrow = weight + (size_t)oc * K;
+    if (oc == 0 && threadIdx.x == 0) { q.scal[0] = sx; q.scal[1] = amax_x; q.scal[2] = inv_sx; q.scal[3] = q.static_amax_x > 0.f ? 1.f : 0.f; }
+    const float *wrow = q.weight + (size_t)oc * K;
     float mx = 0.f;
-    for (int j = threadIdx.x; j < K; j += 256) mx = fmaxf(mx, fabsf(__fmul_rn(wrow[j], s[j])));
+    for (int j = threadIdx.x; j < K; j += 256) mx = fmaxf(mx, fabsf(__fmul_rn(wrow[j], q.s[j])));
     float amax = block_max_1024(mx, sh);
-    if (threadIdx.x == 0) amax_w_out[oc] = amax;   // dynamic per-oc amax of W*s (what a max calibrator collects)
-    if (static_amax_w) amax = static_amax_w[oc];
+    if (threadIdx.x == 0) q.amax_w_out[oc] = amax;   // dynamic per-oc amax of W*s (what a max calibrator collects)
+    if (q.static_amax_w) amax = q.static_amax_w[oc];
     float sw = __fdiv_rn(qmax_w, amax), dv = sw;
     if (amax <= eps) { sw = 0.f; dv = 1.f; }
     for (int j = threadIdx.x; j < K; j += 256) {
-        float q = rintf(__fmul_rn(__fmul_rn(wrow[j], s[j]), sw));
-        q = fminf(fmaxf(q, -qmax_w - 1.f), qmax_w);
-        wq[(size_t)oc * K + j] = (int8_t)(int)q;
+        float v = rintf(__fmul_rn(__fmul_rn(wrow[j], q.s[j]), sw));
+        v = fminf(fmaxf(v, -qmax_w - 1.f), qmax_w);
+        q.wq[(size_t)oc * K + j] = (int8_t)(int)v;
     }
-    if (threadIdx.x == 0) out_mul[oc] = __fmul_rn(inv_sx, __fdiv_rn(1.0f, dv));
+    if (threadIdx.x == 0) q.out_mul[oc] = __fmul_rn(inv_sx, __fdiv_rn(1.0f, dv));
 }
 
 // Fused form of the two kernels above, one launch per layer: every block (= one output channel) recomputes the K smoothing
@@ -284,42 +293,64 @@ __global__ __launch_bounds__(256) void sq_prep_fused_kernel(const float *__restr
     if (threadIdx.x == 0) out_mul[oc] = __fmul_rn(inv_sx, __fdiv_rn(1.0f, dv));
 }
 
-extern "C" int aq3d_sq_prep(const float *pieces, const float *weight, const float *w_colmax,
-                            const aq3d_conv2d_geom *g, float alpha, int32_t w_bits, int32_t a_bits,
-                            float static_amax_x, const float *static_amax_w, float *amax_x_acc, void *params,
-                            void *stream_) {
+extern "C" int aq3d_sq_prep_group(const aq3d_sq_prep_problem *probs, int32_t n, int32_t w_bits, int32_t a_bits, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    AQ3D_REQUIRE(pieces && weight && g && params && amax_x_acc, "aq3d_sq_prep: null argument");
-    AQ3D_REQUIRE(alpha < 0.f || w_colmax, "aq3d_sq_prep: w_colmax needed when smoothing is on");
+    AQ3D_REQUIRE(probs && n >= 1 && n <= AQ3D_SQ_MAX_GROUP, "aq3d_sq_prep_group: n=%d not in 1..%d", n, AQ3D_SQ_MAX_GROUP);
+    AQ3D_REQUIRE(w_bits >= 2 && w_bits <= 8 && a_bits >= 2 && a_bits <= 8, "aq3d_sq_prep: int8 kernel needs bits <= 8 (w=%d a=%d)", w_bits, a_bits);
+    const aq3d_conv2d_geom *g = probs[0].geom;
+    AQ3D_REQUIRE(g, "aq3d_sq_prep: null argument");
     AQ3D_REQUIRE(g->ksize == 1 || g->ksize == 3, "aq3d_sq_prep: ksize=%d", g->ksize);
     AQ3D_REQUIRE(g->stride >= 1 && g->pad >= 0 && g->H >= 3 && g->W >= 3, "aq3d_sq_prep: bad geometry");
-    AQ3D_REQUIRE(w_bits >= 2 && w_bits <= 8 && a_bits >= 2 && a_bits <= 8, "aq3d_sq_prep: int8 kernel needs bits <= 8 (w=%d a=%d)", w_bits, a_bits);
     TapMasks tm;
     if (build_tap_masks(g, &tm) != 0) {
         aq3d_set_error("aq3d_sq_prep: a tap window covers a border piece only partly (H=%d W=%d k=%d s=%d p=%d)", g->H,
                        g->W, g->ksize, g->stride, g->pad);
         return AQ3D_ERR_UNSUPPORTED;
     }
-    const SqLayout l = sq_layout(g->Cin, g->Cout, g->ksize);
-    char *base = (char *)params;
-    float *s = (float *)(base + l.s), *r = (float *)(base + l.r), *mul = (float *)(base + l.mul);
-    float *scal = (float *)(base + l.scal), *amaxw = (float *)(base + l.amaxw);
-    int8_t *wq = (int8_t *)(base + l.wq);
+    SqGroup grp;
+    int max_cout = 0;
+    bool fused_ok = n == 1;
+    for (int i = 0; i < n; ++i) {
+        const aq3d_sq_prep_problem &q = probs[i];
+        AQ3D_REQUIRE(q.pieces && q.weight && q.geom && q.params && q.amax_x_acc, "aq3d_sq_prep: null argument");
+        AQ3D_REQUIRE(q.alpha < 0.f || q.w_colmax, "aq3d_sq_prep: w_colmax needed when smoothing is on");
+        AQ3D_REQUIRE(q.geom->H == g->H && q.geom->W == g->W && q.geom->Cin == g->Cin && q.geom->ksize == g->ksize &&
+                     q.geom->stride == g->stride && q.geom->pad == g->pad, "aq3d_sq_prep_group: problem %d has another geometry", i);
+        const SqLayout l = sq_layout(g->Cin, q.geom->Cout, g->ksize);
+        char *base = (char *)q.params;
+        SqOne &o = grp.p[i];
+        o.pieces = q.pieces; o.w_colmax = q.w_colmax; o.weight = q.weight; o.static_amax_w = q.static_amax_w;
+        o.s = (float *)(base + l.s); o.r = (float *)(base + l.r); o.out_mul = (float *)(base + l.mul);
+        o.scal = (float *)(base + l.scal); o.amax_w_out = (float *)(base + l.amaxw); o.wq = (int8_t *)(base + l.wq);
+        o.amax_x_acc = q.amax_x_acc; o.Cout = q.geom->Cout; o.alpha = q.alpha; o.static_amax_x = q.static_amax_x;
+        max_cout = o.Cout > max_cout ? o.Cout : max_cout;
+    }
+    for (int i = n; i < AQ3D_SQ_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     const int ntaps = g->ksize * g->ksize, K = g->Cin * ntaps;
     const float qa = (float)((1 << (a_bits - 1)) - 1), qw = (float)((1 << (w_bits - 1)) - 1);
     // measured: the fused single launch is SLOWER than the two small ones (13.6-28 us vs 14-16 us per layer; every block
     // redoes 16 x K piece reads), so it stays an experiment
     static const bool fused = getenv("AQ3D_SQ_PREP_FUSED") != nullptr;
-    if (fused && (size_t)K * 4 <= 60 * 1024) {
-        hipLaunchKernelGGL(sq_prep_fused_kernel, dim3(g->Cout), dim3(256), (size_t)K * 4, stream, pieces, w_colmax, weight, g->Cin,
-                           ntaps, tm, alpha, qw, static_amax_w, static_amax_x, qa, s, r, amax_x_acc, scal, wq, mul, amaxw);
+    if (fused && fused_ok && (size_t)K * 4 <= 60 * 1024) {
+        const SqOne &o = grp.p[0];
+        hipLaunchKernelGGL(sq_prep_fused_kernel, dim3(o.Cout), dim3(256), (size_t)K * 4, stream, o.pieces, o.w_colmax, o.weight, g->Cin,
+                           ntaps, tm, o.alpha, qw, o.static_amax_w, o.static_amax_x, qa, o.s, o.r, o.amax_x_acc, o.scal, o.wq, o.out_mul,
+                           o.amax_w_out);
         AQ3D_CHECK_LAUNCH("aq3d_sq_prep");
         return AQ3D_OK;
     }
-    hipLaunchKernelGGL(sq_scales_kernel, dim3(aq3d_div_up(K, 256)), dim3(256), 0, stream, pieces, w_colmax, g->Cin, ntaps, tm,
-                       alpha, s, r, amax_x_acc);
-    hipLaunchKernelGGL(sq_weights_kernel, dim3(g->Cout), dim3(256), 0, stream, weight, s, K, qw, static_amax_w, amax_x_acc,
-                       static_amax_x, qa, scal, wq, mul, amaxw);
+    hipLaunchKernelGGL(sq_scales_kernel, dim3(aq3d_div_up(K, 256), n), dim3(256), 0, stream, grp, g->Cin, ntaps, tm);
+    hipLaunchKernelGGL(sq_weights_kernel, dim3(max_cout, n), dim3(256), 0, stream, grp, K, qw, qa);
     AQ3D_CHECK_LAUNCH("aq3d_sq_prep");
     return AQ3D_OK;
+}
+
+extern "C" int aq3d_sq_prep(const float *pieces, const float *weight, const float *w_colmax,
+                            const aq3d_conv2d_geom *g, float alpha, int32_t w_bits, int32_t a_bits,
+                            float static_amax_x, const float *static_amax_w, float *amax_x_acc, void *params,
+                            void *stream_) {
+    aq3d_sq_prep_problem q;
+    q.pieces = pieces; q.weight = weight; q.w_colmax = w_colmax; q.geom = g; q.alpha = alpha; q.static_amax_x = static_amax_x;
+    q.static_amax_w = static_amax_w; q.amax_x_acc = amax_x_acc; q.params = params;
+    return aq3d_sq_prep_group(&q, 1, w_bits, a_bits, stream_);
 }

@@ -9,6 +9,8 @@ Memory is laid out for a 288 GB HBM3E part: every conv owns its output buffer at
 juggling), gather tables are materialised per index level ([cap, 27] i32), and all per-frame statistics (abs-max
 slots, piece maxima, counters) live in ONE arena cleared by a single memset per frame.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -585,6 +587,7 @@ class Engine:
         nms = pp.NMS_CONFIG
         assert nms.NMS_TYPE == "nms_gpu", "only class-agnostic rotated NMS (nms_gpu) is on the CenterPoint path"
         self.heads = []
+        head_branch_first = len(self.steps)
         for hi, sep in enumerate(head.heads_list):
             hbuf = torch.zeros((B, sH, sW, self.HEAD_LD), dtype=f32, device=dev)
             for name in sep.sep_head_dict:
@@ -615,7 +618,98 @@ class Engine:
                        nms_ws=torch.empty((max(L_.aq3d_nms_workspace_bytes(K), 256),), dtype=torch.uint8, device=dev))
             self.heads.append(rec)
         self.det_counts = torch.zeros((self.NSLOT, B, len(self.heads)), dtype=i32, device=dev)
+        self._group_head_convs(head_branch_first, B)
         self.steps.append(("decode_nms", None))
+
+    def _group_head_convs(self, first, B):
+        """The SeparateHead branches are independent chains of small convs (center_head.py:12-46): reorder them by depth
+        (all first convs, then all second convs ...) and turn runs of same-class convs into ONE grouped launch each
+        (aq3d_conv2d_*_group, aq3d_sq_prep_group; <= 8 problems per launch). The ctypes argument arrays are built here, once."""
+        if os.environ.get("AQ3D_NO_GROUPS") is not None:
+            return
+        tail = self.steps[first:]
+        if not tail or any(k != "conv2d" for k, _ in tail):
+            return
+        recs = [r for _, r in tail]
+        by_out = {r["out"].data_ptr(): r for r in recs}
+        depth = {}
+
+        def depth_of(r):
+            if id(r) not in depth:
+                prod = by_out.get(r["x"].data_ptr())
+                depth[id(r)] = 0 if prod is None or prod is r else depth_of(prod) + 1
+            return depth[id(r)]
+
+        def sig(r):
+            g = r["geom"]
+            base = (depth_of(r), r["kind"], g.H, g.W, g.Cin, g.ksize, g.stride, g.pad, g.deconv)
+            if r["kind"] == "i8":
+                return base + (g.Cout >= 128, r["w_bits"], r["a_bits"])
+            rows = g.Cout * (g.deconv * g.deconv if g.deconv else 1)
+            L = g.H * g.W if g.deconv else g.Ho * g.Wo
+            return base + (0 if rows <= 16 else (1 if (rows <= 64 or L < 128 * 150) else 2), r.get("calib") is not None)
+
+        order = sorted(range(len(recs)), key=lambda i: (depth_of(recs[i]), sig(recs[i]), i))
+        new_steps, i = [], 0
+        while i < len(order):
+            j = i
+            while j + 1 < len(order) and j + 1 - i < 8 and sig(recs[order[j + 1]]) == sig(recs[order[i]]):
+                j += 1
+            grp = [recs[k] for k in order[i:j + 1]]
+            if len(grp) == 1 or grp[0].get("calib") is not None:
+                new_steps.extend(("conv2d", r) for r in grp)
+            else:
+                new_steps.append(("conv2d_group", self._make_group(grp, B)))
+            i = j + 1
+        self.steps[first:] = new_steps
+
+    def _make_group(self, grp, B):
+        kind = grp[0]["kind"]
+        G = dict(kind=kind, recs=grp)
+
+        def problems(b):
+            out = []
+            for r in grp:
+                po = None
+                if r["pieces_out"] is not None:
+                    po = self.arena_view_later(r["pieces_out"][0], (16, r["pieces_out"][1]))
+                out.append(dict(x=r["x"][b], w=r["params"] if kind == "i8" else r["weight"], g=r["geom"], bias=r["bias"],
+                                post_scale=r["post_scale"], post_shift=r["post_shift"], y=r["out"][b], pieces_out=po,
+                                pieces_mode=r["pieces_out"][2] if r["pieces_out"] is not None else 0))
+            return out
+        G["problems"] = problems        # resolved after the arena exists (first run)
+        G["conv_args"] = None
+        G["sq_args"] = None
+        return G
+
+    def arena_view_later(self, handle, shape):
+        return self.arena.view(handle, shape)
+
+    def _run_conv2d_group(self, G, B):
+        recs, kind = G["recs"], G["kind"]
+        if G["conv_args"] is None:       # pointers are stable from here on: build the ctypes arrays once
+            G["conv_args"] = [ops.conv_problems(G["problems"](b)) for b in range(self.batch_cap)]
+            if kind == "i8":
+                G["sq_args"] = ops.sq_prep_problems([dict(
+                    pieces=self.arena.view(r["pieces"], (16, r["geom"].Cin)), weight=r["weight"], w_colmax=r["w_colmax"], g=r["geom"],
+                    alpha=r["alpha"], static_x=r["static_x"], static_w=r["static_w"], amax_x_acc=self.arena.view(r["amax_x_acc"]),
+                    params=r["params"]) for r in recs])
+        if kind == "i8":
+            for r in recs:
+                if r["pieces_owner"]:
+                    g = r["geom"]
+                    with _Timed(self, "piece_absmax"):
+                        for b in range(B):
+                            ops.piece_absmax(r["x"][b], g.H, g.W, g.Cin, g.in_ld, self.arena.view(r["pieces"], (16, g.Cin)))
+            with _Timed(self, "sq_prep"):
+                ops.sq_prep_group(G["sq_args"], recs[0]["w_bits"], recs[0]["a_bits"])
+            with _Timed(self, "conv2d_i8"):
+                for b in range(B):
+                    ops.conv2d_i8_group(G["conv_args"][b])
+        else:
+            with _Timed(self, "conv2d_f32"):
+                for b in range(B):
+                    ops.conv2d_f32_group(G["conv_args"][b])
 
     # ------------------------------------------------------------------ execution
     def _voxelize(self, batch_dict, B):
@@ -900,6 +994,8 @@ class Engine:
                 self._run_spconv(arg)
             elif kind == "conv2d":
                 self._run_conv2d(arg, B)
+            elif kind == "conv2d_group":
+                self._run_conv2d_group(arg, B)
             elif kind == "absmax":
                 if any(r["quant"] is not None and (r["quant"]["on"] or r["quant"]["calib"]) and r["x"] is arg
                        for r in self.sparse_convs):

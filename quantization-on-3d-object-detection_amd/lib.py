@@ -35,6 +35,18 @@ class DecodeCfg(Structure):
                 ("reg_ld", c_int32)]
 
 
+class Conv2dProblem(Structure):
+    _fields_ = [("x", c_void_p), ("weight_or_params", c_void_p), ("geom", POINTER(Conv2dGeom)), ("bias", c_void_p),
+                ("post_scale", c_void_p), ("post_shift", c_void_p), ("y", c_void_p), ("pieces_out", c_void_p),
+                ("pieces_ld", c_int32), ("pieces_mode", c_int32)]
+
+
+class SqPrepProblem(Structure):
+    _fields_ = [("pieces", c_void_p), ("weight", c_void_p), ("w_colmax", c_void_p), ("geom", POINTER(Conv2dGeom)),
+                ("alpha", c_float), ("static_amax_x", c_float), ("static_amax_w", c_void_p), ("amax_x_acc", c_void_p),
+                ("params", c_void_p)]
+
+
 I3 = c_int32 * 3
 P = c_void_p
 
@@ -58,6 +70,9 @@ SIGNATURES = {
     "aq3d_piece_absmax": (c_int32, [P, c_int32, c_int32, c_int32, c_int32, P, P]),
     "aq3d_sq_param_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "aq3d_sq_prep": (c_int32, [P, P, P, POINTER(Conv2dGeom), c_float, c_int32, c_int32, c_float, P, P, P, P]),
+    "aq3d_sq_prep_group": (c_int32, [POINTER(SqPrepProblem), c_int32, c_int32, c_int32, P]),
+    "aq3d_conv2d_i8_group": (c_int32, [POINTER(Conv2dProblem), c_int32, P]),
+    "aq3d_conv2d_f32_group": (c_int32, [POINTER(Conv2dProblem), c_int32, P]),
     "aq3d_conv2d_i8": (c_int32, [P, P, POINTER(Conv2dGeom), P, P, P, P, P, c_int32, c_int32, P]),
     "aq3d_conv2d_f32": (c_int32, [P, P, POINTER(Conv2dGeom), P, P, P, P, P, c_int32, P]),
     "aq3d_center_decode_workspace_bytes": (c_size_t, [POINTER(DecodeCfg)]),

@@ -261,6 +261,46 @@ def conv2d_i8(x, params, g, bias=None, post_scale=None, post_shift=None, out=Non
     return y
 
 
+def _addr(t):
+    return None if t is None else t.data_ptr()
+
+
+def conv_problems(recs):
+    """ctypes array of aq3d_conv2d_problem from dicts(x, w, g, bias, post_scale, post_shift, y, pieces_out, pieces_mode)."""
+    arr = (_lib.Conv2dProblem * len(recs))()
+    for q, r in zip(arr, recs):
+        po = r.get("pieces_out")
+        q.x, q.weight_or_params, q.geom = _addr(r["x"]), _addr(r["w"]), ctypes.pointer(r["g"])
+        q.bias, q.post_scale, q.post_shift = _addr(r.get("bias")), _addr(r.get("post_scale")), _addr(r.get("post_shift"))
+        q.y, q.pieces_out = _addr(r["y"]), _addr(po)
+        q.pieces_ld, q.pieces_mode = (0 if po is None else int(po.shape[1])), int(r.get("pieces_mode", 0))
+    return arr
+
+
+def conv2d_i8_group(problems):
+    """One launch for up to 8 int8 convs of one launch class (problems: ctypes array from conv_problems)."""
+    check(_lib.load().aq3d_conv2d_i8_group(problems, len(problems), _stream()), "aq3d_conv2d_i8_group")
+
+
+def conv2d_f32_group(problems):
+    check(_lib.load().aq3d_conv2d_f32_group(problems, len(problems), _stream()), "aq3d_conv2d_f32_group")
+
+
+def sq_prep_problems(recs):
+    """ctypes array of aq3d_sq_prep_problem from dicts(pieces, weight, w_colmax, g, alpha, static_x, static_w, amax_x_acc, params)."""
+    arr = (_lib.SqPrepProblem * len(recs))()
+    for q, r in zip(arr, recs):
+        q.pieces, q.weight, q.w_colmax, q.geom = _addr(r["pieces"]), _addr(r["weight"]), _addr(r["w_colmax"]), ctypes.pointer(r["g"])
+        q.alpha = float(r["alpha"] if r["alpha"] is not None else -1.0)
+        q.static_amax_x = float(r.get("static_x", 0.0))
+        q.static_amax_w, q.amax_x_acc, q.params = _addr(r.get("static_w")), _addr(r["amax_x_acc"]), _addr(r["params"])
+    return arr
+
+
+def sq_prep_group(problems, w_bits=8, a_bits=8):
+    check(_lib.load().aq3d_sq_prep_group(problems, len(problems), int(w_bits), int(a_bits), _stream()), "aq3d_sq_prep_group")
+
+
 def conv2d_f32(x, weight_k, g, bias=None, post_scale=None, post_shift=None, out=None, pieces_out=None):
     L = _lib.load()
     Ho, Wo = out_hw(g)
