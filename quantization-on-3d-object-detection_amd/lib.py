@@ -100,6 +100,14 @@ def load(path=None):
     if not os.path.isfile(path):
         raise Aq3dError("libaq3d.so not found at %s — build it with `python __graft_entry__.py` "
                         "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+    # libaq3d.so needs libamdhip64.so.7. PyTorch-ROCm ships its own copy of that runtime; the device pointers and stream
+    # handles this host passes in belong to THAT instance, so it has to be in the process first — loading libaq3d.so
+    # before torch pulls in /opt/rocm's runtime as a second instance, and launches on torch's streams then fail with
+    # "no ROCm-capable device" (seen when build() ran before the first `import torch`).
+    try:
+        import torch  # noqa: F401
+    except ImportError:     # a host without torch drives the C ABI with its own HIP runtime
+        pass
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         try:
