@@ -80,15 +80,19 @@ __device__ __forceinline__ int quant_pack4(f32x4 v, f32x4 s, f32x4 r, float sxv)
 }
 
 // ------------------------------------------------------------------ int8 SmoothQuant conv
-template <int TI, int TJ>
-__global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvGroup grp) {
+// NWN = wave columns (2: 256 threads, 4: 512 threads). The K loop is a per-step dependency chain (global load -> quantise ->
+// LDS -> barrier -> MFMA); 8 waves split the staging work of a step in half and give every SIMD a second wave to interleave.
+template <int TI, int TJ, int NWN>
+__global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
+    constexpr int NTH = 128 * NWN;
     const ConvArgs a = grp.p[blockIdx.z];
     if ((int)blockIdx.y * 32 * TI >= a.Cout) return;      // a problem with fewer channel blocks than the widest of its group
     constexpr int BM = 32 * TI;   // output channels per workgroup
-    constexpr int BN = 32 * TJ;   // pixels per workgroup
+    constexpr int BN = 16 * TJ * NWN;   // pixels per workgroup
     constexpr int LD = 80;        // bytes per LDS row: 64 + 16 pad (conflict-free ds_read_b128 of 16 rows)
-    constexpr int PPT = BN / 16;  // pixels per thread when staging X
-    constexpr int WPT = BM / 64;  // 16-byte weight chunks per thread (BM*4 chunks / 256 threads)
+    constexpr int PGS = NTH / 16; // pixel groups of the staging role (16 channel quads x PGS pixels per pass)
+    constexpr int PPT = BN / PGS; // pixels per thread when staging X
+    constexpr int WPT = (BM * 4 + NTH - 1) / NTH;  // 16-byte weight chunks per thread
     static_assert(BM >= 64, "BM >= 64");
     __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * LD];
     __shared__ unsigned int pm[16 * BM];     // piece maxima of this workgroup's outputs (bit patterns of |v|, v >= 0)
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvGroup grp) {
     const int oc0 = blockIdx.y * BM;
     const int cchunks = a.Cin >> 6;
     if (a.pieces_out)
-        for (int i = tid; i < 16 * BM; i += 256) pm[i] = 0u;      // ordered before its use by the K loop's barriers
+        for (int i = tid; i < 16 * BM; i += NTH) pm[i] = 0u;      // ordered before its use by the K loop's barriers
     const int nk = a.ks * a.ks * cchunks;
     const float sx = a.scal[0];
     const bool clamp = a.scal[3] != 0.f;     // calibrated (static) activation amax: codes can exceed +-127 before the clamp
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvGroup grp) {
     unsigned pmask[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int p = pix0 + pg + 16 * i;
+        const int p = pix0 + pg + PGS * i;
         poff[i] = 0;
         pmask[i] = 0u;
         if (p < L) {
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvGroup grp) {
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            const int item = tid + 256 * i;        // (row, 16-byte chunk)
+            const int item = min(tid + NTH * i, BM * 4 - 1);        // (row, 16-byte chunk)
             const int row = min(oc0 + (item >> 2), a.Cout - 1), ch = item & 3;
             wreg[i] = *reinterpret_cast<const i32x4 *>(static_cast<const int8_t *>(a.w) + (size_t)row * K + (size_t)kstep * 64 + ch * 16);
         }
@@ -159,13 +163,13 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvGroup grp) {
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < PPT; ++i)
-            *reinterpret_cast<int *>(Xbuf(buf) + (pg + 16 * i) * LD + cq * 4) =
+            *reinterpret_cast<int *>(Xbuf(buf) + (pg + PGS * i) * LD + cq * 4) =
                 clamp ? quant_pack4<true>(xr[i], sr, rr, ((vbits >> i) & 1u) ? sx : 0.f)
                       : quant_pack4<false>(xr[i], sr, rr, ((vbits >> i) & 1u) ? sx : 0.f);
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
-            const int item = tid + 256 * i;
-            *reinterpret_cast<i32x4 *>(Wbuf(buf) + (item >> 2) * LD + (item & 3) * 16) = wreg[i];
+            const int item = tid + NTH * i;
+            if (BM * 4 % NTH == 0 || item < BM * 4) *reinterpret_cast<i32x4 *>(Wbuf(buf) + (item >> 2) * LD + (item & 3) * 16) = wreg[i];
         }
     };
 
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvGroup grp) {
             af[i] = *reinterpret_cast<const i32x4 *>(Wbuf(buf) + (wm * (BM / 2) + i * 16 + l15) * LD + g * 16);
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
-            bf[j] = *reinterpret_cast<const i32x4 *>(Xbuf(buf) + (wn * (BN / 2) + j * 16 + l15) * LD + g * 16);
+            bf[j] = *reinterpret_cast<const i32x4 *>(Xbuf(buf) + (wn * (BN / NWN) + j * 16 + l15) * LD + g * 16);
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvGroup grp) {
     for (int j = 0; j < TJ; ++j) {
         pcls[j] = 0;
         if (a.pieces_out) {
-            const int p = pix0 + wn * (BN / 2) + j * 16 + l15;
+            const int p = pix0 + wn * (BN / NWN) + j * 16 + l15;
             const int ho = p / a.Wo, wo = p - ho * a.Wo;
             pcls[j] = (a.pieces_mode == 1 && ho > 0 && ho < a.Ho - 1 && wo > 0 && wo < a.Wo - 1)
                           ? -1 : piece_cls(ho, a.Ho) * 4 + piece_cls(wo, a.Wo);
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvGroup grp) {
         }
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-            const int p = pix0 + wn * (BN / 2) + j * 16 + l15;
+            const int p = pix0 + wn * (BN / NWN) + j * 16 + l15;
             if (p >= L) continue;
             f32x4 v;
 #pragma unroll
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) void conv2d_i8_kernel(ConvGroup grp) {
     }
     if (a.pieces_out) {
         __syncthreads();
-        for (int i = tid; i < 16 * BM; i += 256) {
+        for (int i = tid; i < 16 * BM; i += NTH) {
             const unsigned int v = pm[i];
             const int pc = i / BM, oc = oc0 + i % BM;
             if (v != 0u && oc < a.Cout) {
@@ -916,16 +920,18 @@ extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n,
     if (aq3d_div_up(L, 128) * ocb * n < 512) bn = 64;
     if (aq3d_div_up(L, 64) * ocb * n < 512) bn = 32;
     if (force_bn) bn = force_bn;
-#define AQ3D_I8_LAUNCH(TI_, TJ_) \
-    hipLaunchKernelGGL((conv2d_i8_kernel<TI_, TJ_>), dim3(aq3d_div_up(L, 32 * TJ_), ocb, n), dim3(256), 0, stream, grp)
+    static const int nwn_env = getenv("AQ3D_I8_WAVES") ? atoi(getenv("AQ3D_I8_WAVES")) / 2 : 0;
+    const int nwn = nwn_env == 2 || nwn_env == 4 ? nwn_env : 2;      // 8 waves (AQ3D_I8_WAVES=8) measured equal to 4: the VALU op count is what binds
+#define AQ3D_I8_LAUNCH(TI_, TJ_, NWN_) \
+    hipLaunchKernelGGL((conv2d_i8_kernel<TI_, TJ_, NWN_>), dim3(aq3d_div_up(L, 16 * TJ_ * NWN_), ocb, n), dim3(128 * NWN_), 0, stream, grp)
     if (g->Cout >= 128) {
-        if (bn == 128) AQ3D_I8_LAUNCH(4, 4);
-        else if (bn == 64) AQ3D_I8_LAUNCH(4, 2);
-        else AQ3D_I8_LAUNCH(4, 1);
+        if (bn == 128) { if (nwn == 4) AQ3D_I8_LAUNCH(4, 2, 4); else AQ3D_I8_LAUNCH(4, 4, 2); }
+        else if (bn == 64) { if (nwn == 4) AQ3D_I8_LAUNCH(4, 1, 4); else AQ3D_I8_LAUNCH(4, 2, 2); }
+        else AQ3D_I8_LAUNCH(4, 1, 2);
     } else {
-        if (bn == 128) AQ3D_I8_LAUNCH(2, 4);
-        else if (bn == 64) AQ3D_I8_LAUNCH(2, 2);
-        else AQ3D_I8_LAUNCH(2, 1);
+        if (bn == 128) { if (nwn == 4) AQ3D_I8_LAUNCH(2, 2, 4); else AQ3D_I8_LAUNCH(2, 4, 2); }
+        else if (bn == 64) { if (nwn == 4) AQ3D_I8_LAUNCH(2, 1, 4); else AQ3D_I8_LAUNCH(2, 2, 2); }
+        else AQ3D_I8_LAUNCH(2, 1, 2);
     }
 #undef AQ3D_I8_LAUNCH
     AQ3D_CHECK_LAUNCH("aq3d_conv2d_i8");
