@@ -136,36 +136,47 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     f32x4 xr[PPT];
     i32x4 wreg[WPT];
     f32x4 sr, rr;
-    unsigned vbits = 0;   // validity of this step's PPT pixels (bit i)
+    // every global read of the K loop is a bounded buffer load with a 32-bit byte offset: a tap that falls into the zero
+    // padding is an out-of-range offset (returns zeros -> code 0), so there is no validity bookkeeping, no select of the
+    // activation scale and no 64-bit address arithmetic per load (they were a third of the loop's VALU instructions)
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.H * a.W * a.in_ld * 4, 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.Cout * K, 0x00020000);
+    const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)a.s, 0, K * 4, 0x00020000);
+    const auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void *)a.rinv, 0, K * 4, 0x00020000);
+    int wrow_off[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int item = min(tid + NTH * i, BM * 4 - 1);        // (row, 16-byte chunk)
+        wrow_off[i] = min(oc0 + (item >> 2), a.Cout - 1) * K + (item & 3) * 16;
+    }
 
     auto load_step = [&](int kstep) {
         const int tap = kstep / cchunks, c0 = (kstep - tap * cchunks) << 6;
         const int kh = tap / a.ks, kw = tap - kh * a.ks;
         const int toff = (kh * a.W + kw) * a.in_ld + c0;      // wave-uniform
-        const int col = tap * a.Cin + c0 + cq * 4;
-        sr = *reinterpret_cast<const f32x4 *>(a.s + col);
-        rr = *reinterpret_cast<const f32x4 *>(a.rinv + col);
-        vbits = 0;
+        const unsigned col = (unsigned)(tap * a.Cin + c0 + cq * 4) * 4u;
+        sr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, col, 0, 0));
+        rr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, col, 0, 0));
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const bool ok = (pmask[i] >> tap) & 1u;
-            vbits |= ok ? (1u << i) : 0u;
-            const int off = ok ? poff[i] + toff : cq * 4;      // padding pixels read pixel 0 and are zeroed through sxv
-            xr[i] = *reinterpret_cast<const f32x4 *>(a.x + off);
+            const unsigned off = ok ? (unsigned)(poff[i] + toff) * 4u : 0xfffffff0u;
+            xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0));
         }
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int item = min(tid + NTH * i, BM * 4 - 1);        // (row, 16-byte chunk)
-            const int row = min(oc0 + (item >> 2), a.Cout - 1), ch = item & 3;
-            wreg[i] = *reinterpret_cast<const i32x4 *>(static_cast<const int8_t *>(a.w) + (size_t)row * K + (size_t)kstep * 64 + ch * 16);
-        }
+        for (int i = 0; i < WPT; ++i)
+            wreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(wrow_off[i] + kstep * 64), 0, 0));
     };
     auto store_step = [&](int buf) {
+        if (clamp) {
 #pragma unroll
-        for (int i = 0; i < PPT; ++i)
-            *reinterpret_cast<int *>(Xbuf(buf) + (pg + PGS * i) * LD + cq * 4) =
-                clamp ? quant_pack4<true>(xr[i], sr, rr, ((vbits >> i) & 1u) ? sx : 0.f)
-                      : quant_pack4<false>(xr[i], sr, rr, ((vbits >> i) & 1u) ? sx : 0.f);
+            for (int i = 0; i < PPT; ++i)
+                *reinterpret_cast<int *>(Xbuf(buf) + (pg + PGS * i) * LD + cq * 4) = quant_pack4<true>(xr[i], sr, rr, sx);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PPT; ++i)
+                *reinterpret_cast<int *>(Xbuf(buf) + (pg + PGS * i) * LD + cq * 4) = quant_pack4<false>(xr[i], sr, rr, sx);
+        }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int item = tid + NTH * i;
@@ -837,6 +848,8 @@ static int prep_i8(ConvArgs *a, const aq3d_conv2d_problem *q) {
     AQ3D_REQUIRE((g->Cin & 63) == 0, "aq3d_conv2d_i8: Cin=%d must be a multiple of 64", g->Cin);
     AQ3D_REQUIRE((g->Cout & 3) == 0 && (g->out_ld & 3) == 0 && (g->out_coff & 3) == 0, "aq3d_conv2d_i8: Cout/out_ld/out_coff must be multiples of 4");
     AQ3D_REQUIRE(g->deconv == 0, "aq3d_conv2d_i8: deconv unsupported");
+    AQ3D_REQUIRE((int64_t)g->H * g->W * g->in_ld * 4 < (int64_t)0x7fffffff && (int64_t)g->Cout * g->Cin * g->ksize * g->ksize < (int64_t)0x7fffffff,
+                 "aq3d_conv2d_i8: image or weight tensor beyond the 2 GiB buffer-addressing range");
     AQ3D_REQUIRE(g->Ho == (g->H + 2 * g->pad - g->ksize) / g->stride + 1 && g->Wo == (g->W + 2 * g->pad - g->ksize) / g->stride + 1,
                  "aq3d_conv2d_i8: Ho/Wo inconsistent with geometry");
     const SqLayout l = sq_layout(g->Cin, g->Cout, g->ksize);
