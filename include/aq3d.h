@@ -169,6 +169,22 @@ int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant
                 int32_t cin, int32_t cout, int32_t kvol, int32_t flags,
                 float *feats_out, float *absmax_out, void *stream);
 
+/* One layer of a grouped aq3d_spconv launch (the pointer arguments of aq3d_spconv). */
+typedef struct aq3d_spconv_problem {
+    const void *feats_in;
+    const float *act_dequant;
+    const void *weight;
+    const float *w_dequant, *bias, *post_scale, *post_shift, *residual;
+    const int32_t *nbr, *count_out;
+    float *feats_out, *absmax_out;
+} aq3d_spconv_problem;
+
+/* Up to 8 sparse convs of one shape (cin, cout, kvol, modes, capacities) as ONE launch — the per-branch SubMConv2d stacks of
+ * VoxelNeXtHead's SeparateHead (pcdet/models/dense_heads/voxelnext_head.py:13-47). Modes: f32 / int8-coded operands (the
+ * f16-split path takes one layer per call). */
+int aq3d_spconv_group(const aq3d_spconv_problem *problems, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
+                      int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, void *stream);
+
 /* ---------------------------------------------------------------- sparse → dense -------------- */
 
 /* out f32 NHWC [B, H, W, C*D] zero-filled then out[b, y, x, c*D + z] = feats[m, c]. shape = (D, H, W). */

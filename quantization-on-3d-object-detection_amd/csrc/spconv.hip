@@ -36,8 +36,16 @@ struct SpconvArgs {
     int cap_out, cin, kvol, relu;
 };
 
+// up to 8 independent layers of one shape in a single grid (blockIdx.y = problem): the VoxelNeXt head runs 72 small
+// 1x1 sparse convs on one index level
+#define AQ3D_SPCONV_MAX_GROUP 8
+struct SpconvGroup {
+    SpconvArgs p[AQ3D_SPCONV_MAX_GROUP];
+};
+
 template <int CIN_PAD, int COUT, int WR, int WC, bool A_I8, bool W_I8>
-__global__ __launch_bounds__(256) void spconv_kernel(SpconvArgs a) {
+__global__ __launch_bounds__(256) void spconv_kernel(SpconvGroup grp) {
+    const SpconvArgs a = grp.p[blockIdx.y];
     constexpr int TM = 16 * WR;
     constexpr int NT = COUT / (16 * WC);
     constexpr int LDA = CIN_PAD + 4;
@@ -224,7 +232,8 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpconvArgs a) {
 }
 
 template <int CIN_PAD, int COUT, int WR, int WC>
-static int spconv_launch_modes(const SpconvArgs &a, int act_mode, int w_mode, hipStream_t stream) {
+static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int w_mode, hipStream_t stream) {
+    const SpconvArgs &a = grp.p[0];
     constexpr int TM = 16 * WR;
     constexpr size_t lds = (size_t)(TM + COUT) * (CIN_PAD + 4) * 4 + (size_t)TM * 27 * 4 + (size_t)WR * COUT * 4;
     const int tiles = aq3d_div_up(a.cap_out, TM);
@@ -234,7 +243,7 @@ static int spconv_launch_modes(const SpconvArgs &a, int act_mode, int w_mode, hi
         auto kern = spconv_kernel<CIN_PAD, COUT, WR, WC, AI8, WI8>;                                            \
         if (lds > 64 * 1024)                                                                                   \
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);                                        \
+        hipLaunchKernelGGL(kern, dim3(grid, n), dim3(256), lds, stream, grp);                                   \
     } while (0)
     if (act_mode == AQ3D_ACT_I8 && w_mode == AQ3D_W_I8) AQ3D_SPCONV_GO(true, true);
     else if (act_mode == AQ3D_ACT_I8) AQ3D_SPCONV_GO(true, false);
@@ -323,6 +332,9 @@ __global__ __launch_bounds__(256) void spconv_stem_kernel(SpconvArgs a, int cout
     }
 }
 
+extern "C" int aq3d_spconv_group(const aq3d_spconv_problem *probs, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
+                                 int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, void *stream_);
+
 extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
                            int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
                            const float *post_shift, const float *residual, const int32_t *nbr,
@@ -362,13 +374,47 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
             if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
         }
     }
-    SpconvArgs a;
-    a.feats_in = feats_in; a.act_dequant = act_dequant; a.weight = weight; a.w_dequant = w_dequant;
-    a.bias = bias; a.post_scale = post_scale; a.post_shift = post_shift; a.residual = residual;
-    a.nbr = nbr; a.count_out = count_out; a.feats_out = feats_out; a.absmax_out = absmax_out;
-    a.cap_out = cap_out; a.cin = cin; a.kvol = kvol; a.relu = (flags & AQ3D_FLAG_RELU) ? 1 : 0;
+    aq3d_spconv_problem q;
+    q.feats_in = feats_in; q.act_dequant = act_dequant; q.weight = weight; q.w_dequant = w_dequant; q.bias = bias;
+    q.post_scale = post_scale; q.post_shift = post_shift; q.residual = residual; q.nbr = nbr; q.count_out = count_out;
+    q.feats_out = feats_out; q.absmax_out = absmax_out;
+    return aq3d_spconv_group(&q, 1, act_mode, w_mode, cap_out, cap_in, cin, cout, kvol, flags, stream_);
+}
+
+extern "C" int aq3d_spconv_group(const aq3d_spconv_problem *probs, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
+                                 int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)cap_in;
+    AQ3D_REQUIRE(probs && n >= 1 && n <= AQ3D_SPCONV_MAX_GROUP, "aq3d_spconv_group: n=%d not in 1..%d", n, AQ3D_SPCONV_MAX_GROUP);
+    AQ3D_REQUIRE(act_mode != AQ3D_ACT_F16SPLIT && w_mode != AQ3D_W_F16, "aq3d_spconv_group: the f16-split path takes one layer per call (aq3d_spconv)");
+    AQ3D_REQUIRE(cap_out > 0 && kvol >= 1 && kvol <= 27, "aq3d_spconv: cap_out=%d kvol=%d", cap_out, kvol);
+    AQ3D_REQUIRE(cin >= 1 && cin <= 128, "aq3d_spconv: cin=%d not in 1..128", cin);
+    SpconvGroup grp;
+    for (int i = 0; i < n; ++i) {
+        const aq3d_spconv_problem &q = probs[i];
+        AQ3D_REQUIRE(q.feats_in && q.weight && q.nbr && q.count_out && q.feats_out, "aq3d_spconv: null argument");
+        AQ3D_REQUIRE(act_mode != AQ3D_ACT_I8 || ((cin % 16) == 0 && q.act_dequant), "aq3d_spconv: int8 activations need cin%%16==0 and act_dequant");
+        AQ3D_REQUIRE(w_mode != AQ3D_W_I8 || ((cin % 16) == 0 && q.w_dequant), "aq3d_spconv: int8 weights need cin%%16==0 and w_dequant");
+        AQ3D_REQUIRE((q.post_scale == nullptr) == (q.post_shift == nullptr), "aq3d_spconv: post_scale/post_shift must come together");
+        SpconvArgs &a = grp.p[i];
+        a.feats_in = q.feats_in; a.act_dequant = q.act_dequant; a.weight = q.weight; a.w_dequant = q.w_dequant;
+        a.bias = q.bias; a.post_scale = q.post_scale; a.post_shift = q.post_shift; a.residual = q.residual;
+        a.nbr = q.nbr; a.count_out = q.count_out; a.feats_out = q.feats_out; a.absmax_out = q.absmax_out;
+        a.cap_out = cap_out; a.cin = cin; a.kvol = kvol; a.relu = (flags & AQ3D_FLAG_RELU) ? 1 : 0;
+    }
+    for (int i = n; i < AQ3D_SPCONV_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
+    const SpconvArgs &a = grp.p[0];
+    if (n == 1 && act_mode == AQ3D_ACT_I8 && w_mode == AQ3D_W_I8) {
+        static const bool force_f32 = getenv("AQ3D_SPCONV_F32MFMA") != nullptr;   // A/B switch: exact-f32 MFMA path
+        if (!force_f32) {
+            int rc = aq3d_spconv_i8_dispatch((const int8_t *)a.feats_in, a.act_dequant, (const int8_t *)a.weight, a.w_dequant, a.bias,
+                                             a.post_scale, a.post_shift, a.residual, a.nbr, a.count_out, cap_out, cin, cout, kvol,
+                                             a.relu, a.feats_out, a.absmax_out, stream);
+            if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
+        }
+    }
     static const bool no_stem = getenv("AQ3D_SPCONV_NO_STEM") != nullptr;
-    if (!no_stem && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && cin <= 8 && (cout & 3) == 0 && cout <= 64) {
+    if (n == 1 && !no_stem && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && cin <= 8 && (cout & 3) == 0 && cout <= 64) {
         const dim3 grid(aq3d_div_up(cap_out, 256), cout / 4);
         switch (cin) {
 #define AQ3D_STEM(C_) case C_: hipLaunchKernelGGL(spconv_stem_kernel<C_>, grid, dim3(256), 0, stream, a, cout); break;
@@ -380,7 +426,7 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
     }
     const int cin_pad = (cin + 15) / 16 * 16;
 #define AQ3D_SPCONV_CASE(CP, CO, WR_, WC_) \
-    if (cin_pad == CP && cout == CO) return spconv_launch_modes<CP, CO, WR_, WC_>(a, act_mode, w_mode, stream);
+    if (cin_pad == CP && cout == CO) return spconv_launch_modes<CP, CO, WR_, WC_>(grp, n, act_mode, w_mode, stream);
     AQ3D_SPCONV_CASE(16, 16, 4, 1)
     AQ3D_SPCONV_CASE(16, 32, 2, 2)
     AQ3D_SPCONV_CASE(32, 32, 2, 2)

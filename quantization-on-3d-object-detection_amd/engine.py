@@ -126,7 +126,6 @@ class Engine:
         self.max_voxels = int(vcfg.MAX_NUMBER_OF_VOXELS["test"])
         cap_opt = getattr(det, "voxel_capacity", None)
         self.cap = int(cap_opt) if cap_opt else self.max_voxels * self.batch_cap
-        import os
         self.spconv_mode = os.environ.get("AQ3D_SPCONV_MODE", "split")   # "split" (f16 hi/lo activations) | "i8" (coded gather)
         self.arena = _Arena(device)
         self.steps = []
@@ -403,6 +402,7 @@ class Engine:
             self.heads.append(rec)
         self.det_counts = torch.zeros((self.NSLOT, self.batch_cap, len(self.heads)), dtype=i32, device=dev)
         self.dense_convs = []
+        self._group_sparse_head(self.head_first_step)
         self.steps.append(("voxel_decode_nms", None))
 
     # ------------------------------------------------------------------ dense BEV backbone + head
@@ -416,7 +416,6 @@ class Engine:
         self.dense_convs = []
         self._pieces = {}
         self._producers = {}
-        import os
         # piece maxima of a conv's input produced in the epilogue of the conv(s) that wrote it: "1" (default) = int8 producers
         # feeding stride-1 consumers (register-reduced interior maximum, pieces_mode 1); "all" = every producer, exact 16
         # classes (per-element LDS atomics: measured slower than the standalone pass); "0" = always the standalone pass
@@ -621,6 +620,55 @@ class Engine:
         self._group_head_convs(head_branch_first, B)
         self.steps.append(("decode_nms", None))
 
+    def _group_sparse_head(self, first):
+        """VoxelNeXtHead: 6 heads x 6 branches x 2 small sparse convs on ONE index level. Reorder by depth and launch runs of
+        equal-shape layers together (aq3d_spconv_group, <= 8 per launch): 72 launches become 10."""
+        if os.environ.get("AQ3D_NO_GROUPS") is not None:
+            return
+        tail = self.steps[first:]
+        if not tail or any(k != "spconv" for k, _ in tail):
+            return
+        recs = [r for _, r in tail]
+        if any(r["quant"] is not None or r["residual"] is not None for r in recs):
+            return                                   # activation-quantised layers go through the single-layer f16-split path
+        by_out = {id(r["out"]): r for r in recs}
+        depth = {}
+
+        def depth_of(r):
+            if id(r) not in depth:
+                prod = by_out.get(id(r["x"]))
+                depth[id(r)] = 0 if prod is None else depth_of(prod) + 1
+            return depth[id(r)]
+
+        def sig(r):
+            return (depth_of(r), r["cin"], r["cout"], r["kvol"], r["level"], str(r["nbr"]), r["relu"], str(r["weight"].dtype),
+                    r["w_dequant"] is not None)
+
+        order = sorted(range(len(recs)), key=lambda i: (sig(recs[i]), i))
+        new_steps, i = [], 0
+        while i < len(order):
+            j = i
+            while j + 1 < len(order) and j + 1 - i < 8 and sig(recs[order[j + 1]]) == sig(recs[order[i]]):
+                j += 1
+            grp = [recs[k] for k in order[i:j + 1]]
+            new_steps.append(("spconv", grp[0]) if len(grp) == 1 else ("spconv_group", dict(recs=grp, args=None)))
+            i = j + 1
+        self.steps[first:] = new_steps
+
+    def _run_spconv_group(self, G):
+        recs = G["recs"]
+        r0 = recs[0]
+        lv = self.levels[r0["level"]]
+        if G["args"] is None:
+            nbr = self._nbr_of(r0["nbr"], r0["level"])
+            G["args"] = ops.spconv_problems([dict(
+                feats_in=r["x"]["buf"], weight=r["weight"], w_dequant=r["w_dequant"], bias=r["bias"], post_scale=r["post_scale"],
+                post_shift=r["post_shift"], nbr=nbr, count_out=lv["count"], feats_out=r["out"]["buf"],
+                absmax_out=self.arena.view(r["out"]["amax"])) for r in recs])
+            G["w_mode"] = ops.W_I8 if r0["weight"].dtype == torch.int8 else ops.W_F32
+        with _Timed(self, "spconv_c%d" % r0["cout"]):
+            ops.spconv_group(G["args"], ops.ACT_F32, G["w_mode"], self.cap, self.cap, r0["cin"], r0["cout"], r0["kvol"], r0["relu"])
+
     def _group_head_convs(self, first, B):
         """The SeparateHead branches are independent chains of small convs (center_head.py:12-46): reorder them by depth
         (all first convs, then all second convs ...) and turn runs of same-class convs into ONE grouped launch each
@@ -672,7 +720,7 @@ class Engine:
             for r in grp:
                 po = None
                 if r["pieces_out"] is not None:
-                    po = self.arena_view_later(r["pieces_out"][0], (16, r["pieces_out"][1]))
+                    po = self.arena.view(r["pieces_out"][0], (16, r["pieces_out"][1]))
                 out.append(dict(x=r["x"][b], w=r["params"] if kind == "i8" else r["weight"], g=r["geom"], bias=r["bias"],
                                 post_scale=r["post_scale"], post_shift=r["post_shift"], y=r["out"][b], pieces_out=po,
                                 pieces_mode=r["pieces_out"][2] if r["pieces_out"] is not None else 0))
@@ -681,9 +729,6 @@ class Engine:
         G["conv_args"] = None
         G["sq_args"] = None
         return G
-
-    def arena_view_later(self, handle, shape):
-        return self.arena.view(handle, shape)
 
     def _run_conv2d_group(self, G, B):
         recs, kind = G["recs"], G["kind"]
@@ -996,6 +1041,8 @@ class Engine:
                 self._run_conv2d(arg, B)
             elif kind == "conv2d_group":
                 self._run_conv2d_group(arg, B)
+            elif kind == "spconv_group":
+                self._run_spconv_group(arg)
             elif kind == "absmax":
                 if any(r["quant"] is not None and (r["quant"]["on"] or r["quant"]["calib"]) and r["x"] is arg
                        for r in self.sparse_convs):

@@ -41,6 +41,12 @@ class Conv2dProblem(Structure):
                 ("pieces_ld", c_int32), ("pieces_mode", c_int32)]
 
 
+class SpconvProblem(Structure):
+    _fields_ = [("feats_in", c_void_p), ("act_dequant", c_void_p), ("weight", c_void_p), ("w_dequant", c_void_p),
+                ("bias", c_void_p), ("post_scale", c_void_p), ("post_shift", c_void_p), ("residual", c_void_p),
+                ("nbr", c_void_p), ("count_out", c_void_p), ("feats_out", c_void_p), ("absmax_out", c_void_p)]
+
+
 class SqPrepProblem(Structure):
     _fields_ = [("pieces", c_void_p), ("weight", c_void_p), ("w_colmax", c_void_p), ("geom", POINTER(Conv2dGeom)),
                 ("alpha", c_float), ("static_amax_x", c_float), ("static_amax_w", c_void_p), ("amax_x_acc", c_void_p),
@@ -70,6 +76,8 @@ SIGNATURES = {
     "aq3d_piece_absmax": (c_int32, [P, c_int32, c_int32, c_int32, c_int32, P, P]),
     "aq3d_sq_param_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "aq3d_sq_prep": (c_int32, [P, P, P, POINTER(Conv2dGeom), c_float, c_int32, c_int32, c_float, P, P, P, P]),
+    "aq3d_spconv_group": (c_int32, [POINTER(SpconvProblem), c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                    c_int32, P]),
     "aq3d_sq_prep_group": (c_int32, [POINTER(SqPrepProblem), c_int32, c_int32, c_int32, P]),
     "aq3d_conv2d_i8_group": (c_int32, [POINTER(Conv2dProblem), c_int32, P]),
     "aq3d_conv2d_f32_group": (c_int32, [POINTER(Conv2dProblem), c_int32, P]),

@@ -189,6 +189,23 @@ def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequan
     return y
 
 
+def spconv_problems(recs):
+    """ctypes array of aq3d_spconv_problem from dicts(feats_in, act_dequant, weight, w_dequant, bias, post_scale, post_shift,
+    residual, nbr, count_out, feats_out, absmax_out)."""
+    arr = (_lib.SpconvProblem * len(recs))()
+    for q, r in zip(arr, recs):
+        for k in ("feats_in", "act_dequant", "weight", "w_dequant", "bias", "post_scale", "post_shift", "residual", "nbr",
+                  "count_out", "feats_out", "absmax_out"):
+            setattr(q, k, _addr(r.get(k)))
+    return arr
+
+
+def spconv_group(problems, act_mode, w_mode, cap_out, cap_in, cin, cout, kvol, relu):
+    """One launch for up to 8 sparse convs of one shape on the f32 / int8-coded operand path."""
+    check(_lib.load().aq3d_spconv_group(problems, len(problems), int(act_mode), int(w_mode), int(cap_out), int(cap_in), int(cin),
+                                        int(cout), int(kvol), FLAG_RELU if relu else 0, _stream()), "aq3d_spconv_group")
+
+
 # ------------------------------------------------------------------ sparse → dense
 def scatter_dense(feats, coords, count, shape, batch_size, out=None):
     """→ f32 NHWC [B, H, W, C*D], channel = c*D + z (HeightCompression)."""
