@@ -285,20 +285,35 @@ __global__ __launch_bounds__(256) void spconv_stem_kernel(SpconvArgs a, int cout
     const float *x = static_cast<const float *>(a.feats_in);
     const float *w = static_cast<const float *>(a.weight);        // [kvol][cout][CIN]
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    if (row < n) {
-        const int *nb = a.nbr + (size_t)row * a.kvol;
-        for (int k = 0; k < a.kvol; ++k) {
-            const int src = nb[k];
-            if (src < 0) continue;
-            float xv[CIN];
+    // chunks of 9 kernel offsets: the 9 gather-table entries, then the 9 x CIN feature values, are all in flight together
+    // (bounded buffer loads: a missing neighbour / a row past the end is an out-of-range offset -> zeros, no branches); a
+    // zero activation adds +0 to the chain, so the sum equals the one over the present neighbours only
+    const auto rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, n * a.kvol * 4, 0x00020000);
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, 0x7ffffff0, 0x00020000);
+    for (int k0 = 0; k0 < a.kvol; k0 += 9) {
+        int src[9];
 #pragma unroll
-            for (int c = 0; c < CIN; ++c) xv[c] = x[(size_t)src * CIN + c];
-            const float *wk = w + ((size_t)k * cout + o0) * CIN;    // wave-uniform
+        for (int u = 0; u < 9; ++u) {
+            const unsigned off = (row < n && k0 + u < a.kvol) ? (unsigned)((row * a.kvol + k0 + u) * 4) : 0xfffffff0u;
+            src[u] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc_n, off, 0, 0) - ((row < n && k0 + u < a.kvol) ? 0 : 1);
+        }
+        float xv[9][CIN];
+#pragma unroll
+        for (int u = 0; u < 9; ++u)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const unsigned off = src[u] >= 0 ? (unsigned)((src[u] * CIN + c) * 4) : 0xfffffff0u;
+                xv[u][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, off, 0, 0));
+            }
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            if (k0 + u >= a.kvol) break;
+            const float *wk = w + ((size_t)(k0 + u) * cout + o0) * CIN;    // wave-uniform
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float t = 0.f;
 #pragma unroll
-                for (int c = 0; c < CIN; ++c) t = __fmaf_rn(xv[c], wk[j * CIN + c], t);
+                for (int c = 0; c < CIN; ++c) t = __fmaf_rn(xv[u][c], wk[j * CIN + c], t);
                 acc[j] = __fadd_rn(acc[j], t);
             }
         }
