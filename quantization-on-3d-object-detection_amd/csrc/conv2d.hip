@@ -663,20 +663,22 @@ __global__ __launch_bounds__(256) void conv2d_i8_direct_kernel(ConvArgs a) {
 }
 
 // ------------------------------------------------------------------ fp32 conv / transposed conv
-// WM x WN waves; wave tile (TI*16) rows x (TJ*16) pixels; K step = 16 input channels of one tap.
-template <int WM, int WN, int TI, int TJ>
+// WM x WN waves; wave tile (TI*16) rows x (TJ*16) pixels; K step = KS input channels of one tap (KS = 32 halves the
+// barriers but measured no faster than 16, which is what is launched).
+template <int WM, int WN, int TI, int TJ, int KS>
 __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvGroup grp) {
     const ConvArgs a = grp.p[blockIdx.z];
     if ((int)blockIdx.y * WM * TI * 16 >= a.rows_total) return;
     constexpr int BM = WM * TI * 16;
     constexpr int BN = WN * TJ * 16;
-    constexpr int LD = 20;  // floats per LDS row: 16 + 4 pad
+    constexpr int LD = KS + 4;  // floats per LDS row: KS + 4 pad
+    constexpr int QPR = KS / 4; // float4 quads per row and step
     static_assert(WM * WN == 4, "4 waves");
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LD];
     auto Wbuf = [&](int b) -> float * { return smem + b * (BM + BN) * LD; };
     auto Xbuf = [&](int b) -> float * { return smem + b * (BM + BN) * LD + BM * LD; };
-    constexpr int XI = (BN * 4 + 255) / 256;  // float4 items per thread for X (BN rows x 4 quads)
-    constexpr int WI = (BM * 4 + 255) / 256;
+    constexpr int XI = (BN * QPR + 255) / 256;  // float4 items per thread for X (BN rows x QPR quads)
+    constexpr int WI = (BM * QPR + 255) / 256;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave % WM, wn = wave / WM;
@@ -685,15 +687,15 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvGroup grp) {
     const int K = a.Cin * a.ks * a.ks;
     const int pix0 = blockIdx.x * BN;
     const int row0 = blockIdx.y * BM;
-    const int cchunks = a.Cin >> 4;
+    const int cchunks = a.Cin / KS;
     const int nk = a.ks * a.ks * cchunks;
 
     int ph[XI], pw[XI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
         const int item = tid + 256 * i;
-        const int p = pix0 + (item >> 2);
-        if ((item >> 2) < BN && p < L) {
+        const int p = pix0 + item / QPR;
+        if (item / QPR < BN && p < L) {
             int ho = p / a.Wo;
             ph[i] = ho * a.stride - a.pad;
             pw[i] = (p - ho * a.Wo) * a.stride - a.pad;
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvGroup grp) {
     }
     f32x4 xr[XI], wr[WI];
     auto load_step = [&](int kstep) {
-        const int tap = kstep / cchunks, c0 = (kstep - tap * cchunks) << 4;
+        const int tap = kstep / cchunks, c0 = (kstep - tap * cchunks) * KS;
         const int kh = tap / a.ks, kw = tap - kh * a.ks;
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
@@ -712,17 +714,17 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvGroup grp) {
             const int hi = ph[i] + kh, wi = pw[i] + kw;
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
-                v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)hi * a.W + wi) * a.in_ld + c0 + (item & 3) * 4);
+                v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)hi * a.W + wi) * a.in_ld + c0 + (item % QPR) * 4);
             xr[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int item = tid + 256 * i;
-            const int row = item >> 2;
+            const int row = item / QPR;
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (row < BM && row0 + row < a.rows_total)
                 v = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(a.w) + (size_t)(row0 + row) * K +
-                                                      (size_t)tap * a.Cin + c0 + (item & 3) * 4);
+                                                      (size_t)tap * a.Cin + c0 + (item % QPR) * 4);
             wr[i] = v;
         }
     };
@@ -730,12 +732,12 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvGroup grp) {
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const int item = tid + 256 * i;
-            if ((item >> 2) < BN) *reinterpret_cast<f32x4 *>(Xbuf(buf) + (item >> 2) * LD + (item & 3) * 4) = xr[i];
+            if (item / QPR < BN) *reinterpret_cast<f32x4 *>(Xbuf(buf) + (item / QPR) * LD + (item % QPR) * 4) = xr[i];
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int item = tid + 256 * i;
-            if ((item >> 2) < BM) *reinterpret_cast<f32x4 *>(Wbuf(buf) + (item >> 2) * LD + (item & 3) * 4) = wr[i];
+            if (item / QPR < BM) *reinterpret_cast<f32x4 *>(Wbuf(buf) + (item / QPR) * LD + (item % QPR) * 4) = wr[i];
         }
     };
 
@@ -746,22 +748,25 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvGroup grp) {
         for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto mma_step = [&](int buf) {
-        f32x4 af[TI], bf[TJ];
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
-            af[i] = *reinterpret_cast<const f32x4 *>(Wbuf(buf) + (wm * TI * 16 + i * 16 + l15) * LD + g * 4);
+        for (int kk = 0; kk < KS / 16; ++kk) {
+            f32x4 af[TI], bf[TJ];
 #pragma unroll
-        for (int j = 0; j < TJ; ++j)
-            bf[j] = *reinterpret_cast<const f32x4 *>(Xbuf(buf) + (wn * TJ * 16 + j * 16 + l15) * LD + g * 4);
+            for (int i = 0; i < TI; ++i)
+                af[i] = *reinterpret_cast<const f32x4 *>(Wbuf(buf) + (wm * TI * 16 + i * 16 + l15) * LD + kk * 16 + g * 4);
 #pragma unroll
-        for (int i = 0; i < TI; ++i)
+            for (int j = 0; j < TJ; ++j)
+                bf[j] = *reinterpret_cast<const f32x4 *>(Xbuf(buf) + (wn * TJ * 16 + j * 16 + l15) * LD + kk * 16 + g * 4);
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-            }
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
     };
     load_step(0);
     store_step(0);
@@ -1004,11 +1009,11 @@ extern "C" int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *probs, int32_t n
     }
     for (int i = n; i < AQ3D_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     if (cls == 0) {
-        hipLaunchKernelGGL((conv2d_f32_kernel<1, 4, 1, 2>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
+        hipLaunchKernelGGL((conv2d_f32_kernel<1, 4, 1, 2, 16>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
     } else if (cls == 1) {
-        hipLaunchKernelGGL((conv2d_f32_kernel<2, 2, 2, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
+        hipLaunchKernelGGL((conv2d_f32_kernel<2, 2, 2, 2, 16>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
     } else {
-        hipLaunchKernelGGL((conv2d_f32_kernel<2, 2, 4, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 128), n), dim3(256), 0, stream, grp);
+        hipLaunchKernelGGL((conv2d_f32_kernel<2, 2, 4, 2, 16>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 128), n), dim3(256), 0, stream, grp);
     }
     AQ3D_CHECK_LAUNCH("aq3d_conv2d_f32");
     return AQ3D_OK;
