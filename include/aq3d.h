@@ -169,6 +169,17 @@ int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant
                 int32_t cin, int32_t cout, int32_t kvol, int32_t flags,
                 float *feats_out, float *absmax_out, void *stream);
 
+/* aq3d_spconv with an optional scratch buffer (aq3d_spconv_workspace_bytes; ZEROED ONCE by the caller, the library keeps it
+ * consistent afterwards; one launch at a time per buffer). With it, the wide-tile f16-split kernel lets two workgroups share
+ * a 128-row tile (half of the kernel offsets each) while the live row count leaves CUs idle — decided on the device. */
+size_t aq3d_spconv_workspace_bytes(int32_t cap_out, int32_t cout);
+int aq3d_spconv_ws(const void *feats_in, int32_t act_mode, const float *act_dequant,
+                   const void *weight, int32_t w_mode, const float *w_dequant,
+                   const float *bias, const float *post_scale, const float *post_shift, const float *residual,
+                   const int32_t *nbr, const int32_t *count_out, int32_t cap_out, int32_t cap_in,
+                   int32_t cin, int32_t cout, int32_t kvol, int32_t flags,
+                   float *feats_out, float *absmax_out, void *workspace, size_t workspace_bytes, void *stream);
+
 /* One layer of a grouped aq3d_spconv launch (the pointer arguments of aq3d_spconv). */
 typedef struct aq3d_spconv_problem {
     const void *feats_in;

@@ -265,7 +265,7 @@ int aq3d_spconv_direct_dispatch(const void *feats_split, unsigned feats_bytes, c
 int aq3d_spconv_wide_dispatch(const void *feats_split, unsigned feats_bytes, const void *weight_f16, const float *w_dequant,
                               const float *bias, const float *post_scale, const float *post_shift, const float *residual,
                               const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
-                              float *feats_out, float *absmax_out, hipStream_t stream);
+                              float *feats_out, float *absmax_out, void *ws, size_t ws_bytes, hipStream_t stream);
 int aq3d_spconv_split_dispatch(const void *feats_split, unsigned feats_bytes, const void *weight_f16, const float *w_dequant,
                                const float *bias, const float *post_scale, const float *post_shift, const float *residual,
                                const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
@@ -350,11 +350,34 @@ __global__ __launch_bounds__(256) void spconv_stem_kernel(SpconvArgs a, int cout
 extern "C" int aq3d_spconv_group(const aq3d_spconv_problem *probs, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
                                  int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, void *stream_);
 
+extern "C" int aq3d_spconv_ws(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
+                              int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
+                              const float *post_shift, const float *residual, const int32_t *nbr,
+                              const int32_t *count_out, int32_t cap_out, int32_t cap_in, int32_t cin, int32_t cout,
+                              int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, void *workspace,
+                              size_t workspace_bytes, void *stream_);
+
+extern "C" size_t aq3d_spconv_workspace_bytes(int32_t cap_out, int32_t cout) {
+    if (cap_out < 1 || cout < 1) return 0;
+    const size_t tiles = (size_t)aq3d_div_up(cap_out, 128);
+    return ((tiles * 4 + 255) & ~(size_t)255) + tiles * 2 * 128 * (size_t)cout * 4;
+}
+
 extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
                            int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
                            const float *post_shift, const float *residual, const int32_t *nbr,
                            const int32_t *count_out, int32_t cap_out, int32_t cap_in, int32_t cin, int32_t cout,
                            int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, void *stream_) {
+    return aq3d_spconv_ws(feats_in, act_mode, act_dequant, weight, w_mode, w_dequant, bias, post_scale, post_shift, residual, nbr,
+                          count_out, cap_out, cap_in, cin, cout, kvol, flags, feats_out, absmax_out, nullptr, 0, stream_);
+}
+
+extern "C" int aq3d_spconv_ws(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
+                              int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
+                              const float *post_shift, const float *residual, const int32_t *nbr,
+                              const int32_t *count_out, int32_t cap_out, int32_t cap_in, int32_t cin, int32_t cout,
+                              int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, void *workspace,
+                              size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AQ3D_REQUIRE(feats_in && weight && nbr && count_out && feats_out, "aq3d_spconv: null argument");
     AQ3D_REQUIRE(cap_out > 0 && kvol >= 1 && kvol <= 27, "aq3d_spconv: cap_out=%d kvol=%d", cap_out, kvol);
@@ -373,7 +396,7 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
             if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
             rc = aq3d_spconv_wide_dispatch(feats_in, (unsigned)((int64_t)cap_in * cin * 4), weight, w_dequant, bias,
                                            post_scale, post_shift, residual, nbr, count_out, cap_out, cin, cout, kvol,
-                                           (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, stream);
+                                           (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, workspace, workspace_bytes, stream);
             if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
         }
         return aq3d_spconv_split_dispatch(feats_in, (unsigned)((int64_t)cap_in * cin * 4), weight, w_dequant, bias, post_scale,

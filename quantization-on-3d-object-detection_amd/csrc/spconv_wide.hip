@@ -35,6 +35,9 @@ struct SpconvWideArgs {
     int cap_out, kvol, relu;
     unsigned feats_bytes;
     long long *stamps;        // STAMP builds (AQ3D_WIDE_DEBUG=1): cycle sums over (workgroup, wave 0, unit)
+    float *partial;           // split mode scratch: [tiles][2][128 * COUT] accumulator images (NULL: never split)
+    int *flags;               // split mode: [tiles] arrival counters, zero between launches (self-resetting)
+    int split_below;          // split the kernel offsets of a tile over two workgroups while tiles < split_below
 };
 
 template <int CIN, int COUT, bool STAMP>
@@ -65,7 +68,19 @@ __global__ __launch_bounds__(256) void spconv_wide_kernel(SpconvWideArgs a) {
     const int kvol = a.kvol;
     int n = *a.count_out;
     if (n > a.cap_out) n = a.cap_out;
-    const int row0 = blockIdx.x * TM;
+    // Tile quantisation: with T tiles on 256 CUs the kernel lasts ceil(T / 256) tile times (299 tiles: 2 instead of 1.17).
+    // While T is small, TWO workgroups share a tile, each taking half of its live kernel offsets; the one that finishes
+    // second adds the other's accumulator image (global scratch, arrival counter) and runs the epilogue. Sums are identical
+    // whichever arrives last (a + b == b + a). The decision is taken on the device from the live row count.
+    const int ntiles_all = (n + TM - 1) / TM;
+    const bool split = a.partial != nullptr && kvol >= 8 && ntiles_all < a.split_below;
+    // partner workgroups are the second half of the grid: consecutive block ids go round-robin over the 8 XCDs, so pairing
+    // (2t, 2t+1) would park every unsplit launch on four of them
+    const int grid_tiles = a.partial != nullptr ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+    const int tile = (int)blockIdx.x % grid_tiles;
+    const int half = (int)blockIdx.x / grid_tiles;
+    if (!split && half) return;
+    const int row0 = tile * TM;
     if (row0 >= n) return;
     const long long tstart = STAMP ? __builtin_amdgcn_s_memtime() : 0;
     const auto rsrc_f = __builtin_amdgcn_make_buffer_rsrc((void *)a.feats, 0, (int)a.feats_bytes, 0x00020000);
@@ -92,7 +107,14 @@ __global__ __launch_bounds__(256) void spconv_wide_kernel(SpconvWideArgs a) {
         if (bits) atomicOr(&mask_s[0], bits);
     }
     __syncthreads();
-    const int live = mask_s[0];
+    int live = mask_s[0];
+    if (split) {                                        // this workgroup's share: the lower / upper half of the live offsets
+        const int want = (__popc(live) + 1) >> 1;
+        int low = 0, cnt = 0;
+        for (int k = 0; k < kvol && cnt < want; ++k)
+            if ((live >> k) & 1) { low |= 1 << k; ++cnt; }
+        live = half ? (live & ~low) : low;
+    }
 
     f32x4 acc[RT][NT];
 #pragma unroll
@@ -237,6 +259,39 @@ __global__ __launch_bounds__(256) void spconv_wide_kernel(SpconvWideArgs a) {
         atomicAdd((unsigned long long *)&a.stamps[7], (unsigned long long)stf);
     }
 
+    if (split) {
+        // accumulator image: thread-major, 16 bytes per (thread, rt, nt) -> coalesced 16-byte accesses
+        float *mine = a.partial + ((size_t)tile * 2 + half) * (TM * COUT);
+        const float *other = a.partial + ((size_t)tile * 2 + (half ^ 1)) * (TM * COUT);
+        __shared__ int s_arrival;
+        if (tid == 0) s_arrival = __hip_atomic_load(&a.flags[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        int arrival = s_arrival;                        // 1: the partner has already published its image -> no need to write ours
+        if (arrival == 0) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    *reinterpret_cast<f32x4 *>(mine + ((size_t)(rt * NT + nt) * 256 + tid) * 4) = acc[rt][nt];
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) s_arrival = atomicAdd(&a.flags[tile], 1);
+            __syncthreads();
+            arrival = s_arrival;
+            if (arrival == 0) return;                   // first to arrive: the partner finishes the tile
+        }
+        __threadfence();
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 o = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(other + ((size_t)(rt * NT + nt) * 256 + tid) * 4));
+                acc[rt][nt] = half ? (f32x4){__fadd_rn(o.x, acc[rt][nt].x), __fadd_rn(o.y, acc[rt][nt].y), __fadd_rn(o.z, acc[rt][nt].z), __fadd_rn(o.w, acc[rt][nt].w)}
+                                   : (f32x4){__fadd_rn(acc[rt][nt].x, o.x), __fadd_rn(acc[rt][nt].y, o.y), __fadd_rn(acc[rt][nt].z, o.z), __fadd_rn(acc[rt][nt].w, o.w)};
+            }
+        if (tid == 0) a.flags[tile] = 0;                // ready for the next launch (stream-ordered)
+    }
+
     // ---- epilogue (D layout: col = lane&15 -> out channel, row = 4g + reg -> tile row)
     float cmax[NT];
 #pragma unroll
@@ -280,10 +335,19 @@ __global__ __launch_bounds__(256) void spconv_wide_kernel(SpconvWideArgs a) {
 }
 
 template <int CIN, int COUT>
-static int launch_wide(const SpconvWideArgs &a, hipStream_t stream, bool stamp) {
+static int launch_wide(const SpconvWideArgs &a_in, hipStream_t stream, bool stamp, void *ws, size_t ws_bytes) {
+    SpconvWideArgs a = a_in;
+    const int cap_tiles = aq3d_div_up(a.cap_out, 128);
+    const size_t need = (((size_t)cap_tiles * 4 + 255) & ~(size_t)255) + (size_t)cap_tiles * 2 * 128 * COUT * 4;
+    static const int split_below = getenv("AQ3D_WIDE_SPLIT_BELOW") ? atoi(getenv("AQ3D_WIDE_SPLIT_BELOW")) : 448;
+    a.partial = nullptr; a.flags = nullptr; a.split_below = split_below;
+    if (ws && ws_bytes >= need && split_below > 0 && a.kvol >= 8 && !stamp) {
+        a.flags = (int *)ws;                                                   // flags first: zeroed once by the owner
+        a.partial = (float *)((char *)ws + (((size_t)cap_tiles * 4 + 255) & ~(size_t)255));
+    }
     constexpr int UC = CIN < 64 ? CIN : 64;
     constexpr size_t lds = (size_t)2 * COUT * (UC == 64 ? UC : UC + 8) * 2 + (size_t)128 * 27 * 4 + (size_t)4 * COUT * 4 + 64;
-    const int grid = aq3d_div_up(a.cap_out, 128);
+    const int grid = aq3d_div_up(a.cap_out, 128) * (a.partial ? 2 : 1);
     auto kern = spconv_wide_kernel<CIN, COUT, false>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (stamp) {          // diagnostic path only (instrumented instantiation): blocking, prints the stamp averages of this launch
@@ -312,7 +376,7 @@ static int launch_wide(const SpconvWideArgs &a, hipStream_t stream, bool stamp) 
 int aq3d_spconv_wide_dispatch(const void *feats_split, unsigned feats_bytes, const void *weight_f16, const float *w_dequant,
                               const float *bias, const float *post_scale, const float *post_shift, const float *residual,
                               const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
-                              float *feats_out, float *absmax_out, hipStream_t stream) {
+                              float *feats_out, float *absmax_out, void *ws, size_t ws_bytes, hipStream_t stream) {
     static const bool off = getenv("AQ3D_SPCONV_WIDE") != nullptr && atoi(getenv("AQ3D_SPCONV_WIDE")) == 0;
     if (off || kvol > 27) return AQ3D_ERR_UNSUPPORTED;
     SpconvWideArgs a;
@@ -322,9 +386,9 @@ int aq3d_spconv_wide_dispatch(const void *feats_split, unsigned feats_bytes, con
     a.feats_bytes = feats_bytes;
     static const bool stamp = getenv("AQ3D_WIDE_DEBUG") != nullptr && atoi(getenv("AQ3D_WIDE_DEBUG")) != 0;
     a.stamps = nullptr;
-    if (cin == 32 && cout == 64) return launch_wide<32, 64>(a, stream, stamp);
-    if (cin == 64 && cout == 64) return launch_wide<64, 64>(a, stream, stamp);
-    if (cin == 64 && cout == 128) return launch_wide<64, 128>(a, stream, stamp);
-    if (cin == 128 && cout == 128) return launch_wide<128, 128>(a, stream, stamp);
+    if (cin == 32 && cout == 64) return launch_wide<32, 64>(a, stream, stamp, ws, ws_bytes);
+    if (cin == 64 && cout == 64) return launch_wide<64, 64>(a, stream, stamp, ws, ws_bytes);
+    if (cin == 64 && cout == 128) return launch_wide<64, 128>(a, stream, stamp, ws, ws_bytes);
+    if (cin == 128 && cout == 128) return launch_wide<128, 128>(a, stream, stamp, ws, ws_bytes);
     return AQ3D_ERR_UNSUPPORTED;
 }

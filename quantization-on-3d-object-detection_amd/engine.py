@@ -131,6 +131,7 @@ class Engine:
         self.steps = []
         self.tensors = {}
         self._voxel_ws = None
+        self._sp_ws = None
         if isinstance(det.backbone_3d, VoxelResBackBone8xVoxelNeXt):
             self.fully_sparse = True
             self._build_voxelnext(det.backbone_3d, det.dense_head)
@@ -813,6 +814,13 @@ class Engine:
             return self.levels[ref[1]]["down"]["nbr"]
         return self.levels[ref]["nbr"]
 
+    def _spconv_ws(self):
+        """Scratch for the split-tile mode of the wide kernel (AQ3D_WIDE_SPLIT=1; measured SLOWER than whole tiles — the doubled
+        prologue, the 64 KB accumulator hand-over and co-residency cost more than the idle CUs — so it is off by default)."""
+        if self._sp_ws is None:
+            self._sp_ws = ops.spconv_workspace(self.cap, 128, self.device) if os.environ.get("AQ3D_WIDE_SPLIT", "0") != "0" else False
+        return self._sp_ws if self._sp_ws is not False else None
+
     def _run_spconv(self, rec):
         lv = self.levels[rec["level"]]
         x = rec["x"]
@@ -843,7 +851,7 @@ class Engine:
             ops.spconv(feats, rec["weight"], nbr, lv["count"], rec["cout"], act_dequant=act_dq, w_dequant=rec["w_dequant"],
                        bias=rec["bias"], post_scale=rec["post_scale"], post_shift=rec["post_shift"],
                        residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
-                       absmax_out=self.arena.view(out["amax"]), out=out["buf"])
+                       absmax_out=self.arena.view(out["amax"]), out=out["buf"], workspace=self._spconv_ws())
 
     def _run_conv2d(self, rec, B):
         g = rec["geom"]

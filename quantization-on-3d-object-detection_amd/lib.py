@@ -76,6 +76,9 @@ SIGNATURES = {
     "aq3d_piece_absmax": (c_int32, [P, c_int32, c_int32, c_int32, c_int32, P, P]),
     "aq3d_sq_param_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "aq3d_sq_prep": (c_int32, [P, P, P, POINTER(Conv2dGeom), c_float, c_int32, c_int32, c_float, P, P, P, P]),
+    "aq3d_spconv_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "aq3d_spconv_ws": (c_int32, [P, c_int32, P, P, c_int32, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32,
+                                 c_int32, P, P, P, c_size_t, P]),
     "aq3d_spconv_group": (c_int32, [POINTER(SpconvProblem), c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, P]),
     "aq3d_sq_prep_group": (c_int32, [POINTER(SqPrepProblem), c_int32, c_int32, c_int32, P]),

@@ -173,7 +173,7 @@ FLAG_RELU = 1
 
 
 def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequant=None, bias=None, post_scale=None,
-           post_shift=None, residual=None, relu=False, absmax_out=None, out=None):
+           post_shift=None, residual=None, relu=False, absmax_out=None, out=None, workspace=None):
     """Gather-GEMM sparse conv. feats_in f32|i8 [*, cin]; weight f32|i8 [kvol, cout, cin]; nbr i32 [cap_out, kvol]."""
     L = _lib.load()
     cap_out, kvol = nbr.shape
@@ -182,11 +182,16 @@ def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequan
     cin = feats_in.shape[1] // 2 if act_mode == ACT_F16SPLIT else feats_in.shape[1]
     assert weight.shape == (kvol, cout, cin), (tuple(weight.shape), (kvol, cout, cin))
     y = out if out is not None else torch.empty((cap_out, cout), dtype=f32, device=nbr.device)
-    check(L.aq3d_spconv(_p(feats_in), act_mode, _p(act_dequant), _p(weight), w_mode, _p(w_dequant), _p(bias),
-                        _p(post_scale), _p(post_shift), _p(residual), _p(nbr), _p(count_out), cap_out, int(feats_in.shape[0]),
-                        cin, cout, kvol,
-                        FLAG_RELU if relu else 0, _p(y), _p(absmax_out), _stream()), "aq3d_spconv")
+    check(L.aq3d_spconv_ws(_p(feats_in), act_mode, _p(act_dequant), _p(weight), w_mode, _p(w_dequant), _p(bias),
+                           _p(post_scale), _p(post_shift), _p(residual), _p(nbr), _p(count_out), cap_out, int(feats_in.shape[0]),
+                           cin, cout, kvol, FLAG_RELU if relu else 0, _p(y), _p(absmax_out), _p(workspace),
+                           0 if workspace is None else workspace.numel() * workspace.element_size(), _stream()), "aq3d_spconv")
     return y
+
+
+def spconv_workspace(cap_out, cout, device):
+    """Zeroed scratch for spconv(workspace=...): lets the wide kernel split a tile's offsets over two workgroups."""
+    return torch.zeros((_lib.load().aq3d_spconv_workspace_bytes(int(cap_out), int(cout)),), dtype=torch.uint8, device=device)
 
 
 def spconv_problems(recs):
