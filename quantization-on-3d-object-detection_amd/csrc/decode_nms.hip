@@ -57,6 +57,61 @@ __device__ __forceinline__ void bitonic_sort_desc(u64 *keys, int n) {
     }
 }
 
+// Same sort, far fewer barriers: every wave keeps 128 consecutive keys in registers (lane l: elements base + l and
+// base + 64 + l); compare-exchange distances below 64 are wave shuffles, distance 64 is a swap inside the lane, and only
+// distances >= 128 go through LDS behind a barrier. For n = 2048 that is 10 barrier rounds instead of 66 — the decode
+// stage is a single-workgroup latency chain at the end of the frame.
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
+    const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)(v >> 32), m, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ void bitonic_sort_desc_hybrid(u64 *keys, int n) {       // n: power of two, 128 <= n <= 128 * waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int base = wave * 128;
+    const bool active = base < n;
+    u64 e0 = active ? keys[base + lane] : 0ull, e1 = active ? keys[base + 64 + lane] : 0ull;
+    auto local_stages = [&](int k, int jmax) {       // sub-stages j = jmax .. 1 (jmax <= 64) of merge size k, in registers
+        for (int j = jmax; j > 0; j >>= 1) {
+            if (j == 64) {
+                const bool desc = ((base + lane) & k) == 0;
+                const bool sw = desc ? (e0 < e1) : (e0 > e1);
+                const u64 a = sw ? e1 : e0, b = sw ? e0 : e1;
+                e0 = a; e1 = b;
+            } else {
+                const u64 p0 = shfl_xor_u64(e0, j), p1 = shfl_xor_u64(e1, j);
+                const bool upper = (lane & j) != 0;           // this lane holds the element with the larger index of the pair
+                const bool d0 = ((base + lane) & k) == 0, d1 = ((base + 64 + lane) & k) == 0;
+                // descending block: the lower index keeps the larger key
+                e0 = (d0 != upper) ? (e0 > p0 ? e0 : p0) : (e0 < p0 ? e0 : p0);
+                e1 = (d1 != upper) ? (e1 > p1 ? e1 : p1) : (e1 < p1 ? e1 : p1);
+            }
+        }
+    };
+    for (int k = 2; k <= n; k <<= 1) {
+        int j = k >> 1;
+        if (j >= 128) {
+            // distances >= 128: through LDS, one barrier pair per sub-stage
+            if (active) { keys[base + lane] = e0; keys[base + 64 + lane] = e1; }
+            __syncthreads();
+            for (; j >= 128; j >>= 1) {
+                for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const u64 a = keys[i], b = keys[ixj];
+                        const bool desc = (i & k) == 0;
+                        if (desc ? (a < b) : (a > b)) { keys[i] = b; keys[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+            if (active) { e0 = keys[base + lane]; e1 = keys[base + 64 + lane]; }
+        }
+        if (active) local_stages(k, j < 64 ? j : 64);
+    }
+    if (active) { keys[base + lane] = e0; keys[base + 64 + lane] = e1; }
+    __syncthreads();
+}
+
 __device__ __forceinline__ float sigmoidf_dev(float x) { return __fdiv_rn(1.0f, __fadd_rn(1.0f, expf(-x))); }
 
 // ------------------------------------------------------------------ stage 1: per-class top-K (radix select + sort)
@@ -246,7 +301,7 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
         }
     }
     __syncthreads();
-    bitonic_sort_desc(sel, Kpad);
+    // unsorted: stage 2 orders everything by (score desc, class asc, pixel asc) itself
     for (int i = threadIdx.x; i < K; i += blockDim.x) out[(size_t)cls * K + i] = (i < Keff) ? sel[i] : 0ull;
 }
 
@@ -267,14 +322,18 @@ __global__ __launch_bounds__(1024) void decode_kernel(const u64 *__restrict__ ca
     for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
         u64 v = 0ull;
         if (i < ncand) {
-            u64 cv = cand[i];
-            v = (cv & 0xffffffff00000000ull) | (u64)(0xffffffffu - (unsigned int)i);
+            const u64 cv = cand[i];
+            // ties: class-major, then pixel index ascending — what torch.topk over the [ncls, K] matrix of per-class
+            // lists (each ordered by score desc / pixel asc) yields; independent of the slot order inside a class
+            const unsigned pixel = 0xffffffffu - (unsigned int)(cv & 0xffffffffull);
+            v = (cv & 0xffffffff00000000ull) | (u64)(0xffffffffu - (((unsigned int)(i / K) << 27) | pixel));
             if (cv == 0ull) v = 0ull;  // empty slot
         }
         keys[i] = v;
     }
     __syncthreads();
-    bitonic_sort_desc(keys, Npad);
+    if (Npad >= 128 && Npad <= 2048 && blockDim.x == 1024) bitonic_sort_desc_hybrid(keys, Npad);
+    else bitonic_sort_desc(keys, Npad);
 
     const int nbox = q.c.has_vel ? 9 : 7;
     const int t = threadIdx.x;
@@ -284,9 +343,9 @@ __global__ __launch_bounds__(1024) void decode_kernel(const u64 *__restrict__ ca
     int label = 0;
     if (t < K && keys[t] != 0ull) {
         const u64 kv = keys[t];
-        const int pos = (int)(0xffffffffu - (unsigned int)(kv & 0xffffffffull));
-        label = pos / K;
-        const int pix = (int)(0xffffffffu - (unsigned int)(cand[pos] & 0xffffffffull));
+        const unsigned cp = 0xffffffffu - (unsigned int)(kv & 0xffffffffull);
+        label = (int)(cp >> 27);
+        const int pix = (int)(cp & 0x07ffffffu);
         score = __uint_as_float((unsigned int)(kv >> 32));
         int yi, xi;
         if (q.coords) { yi = q.coords[(size_t)pix * 4 + 2]; xi = q.coords[(size_t)pix * 4 + 3]; }
