@@ -258,9 +258,10 @@ int aq3d_sq_prep_group(const aq3d_sq_prep_problem *problems, int32_t n, int32_t 
  *   epilogue: v = acc * out_mul[o] + bias[o]; y = v * post_scale[o] + post_shift[o]; relu.
  *   pieces_out (may be NULL): f32 [16, pieces_ld] piece abs-max accumulator of the OUTPUT tensor (same definition as
  *   aq3d_piece_absmax over the output image, column out_coff + o), so that the next SmoothQuant conv needs no extra pass;
- *   zeroed by the caller once per frame. pieces_mode 0: the 16 classes exactly; 1: the abs-max over the whole
- *   interior goes to class (interior-even row, interior-even column) alone and the other three interior classes stay 0 —
- *   exact for every consumer with stride 1 (its tap windows always take the max over all four) and much cheaper. */
+ *   zeroed by the caller once per frame. pieces_mode 0: the 16 classes exactly; 1: interior pixels are not separated
+ *   by parity — each workgroup's interior abs-max goes to one of the four interior classes (their maximum is the
+ *   abs-max over the whole interior): exact for every consumer with stride 1, whose tap windows always take the max over
+ *   all four, and much cheaper to produce. */
 int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_conv2d_geom *g,
                    const float *bias, const float *post_scale, const float *post_shift,
                    float *y, float *pieces_out, int32_t pieces_ld, int32_t pieces_mode, void *stream);

@@ -289,10 +289,15 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
             const int pc = i / BM, oc = oc0 + i % BM;
             if (v != 0u && oc < a.Cout) {
                 unsigned int *dst = reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc * a.pieces_ld + a.out_coff + oc;
-                // mode 1: the merged interior maximum lives in class (2,2) alone — the other three interior slots stay zero and
-                // every stride-1 consumer takes the max over all four; fire-and-forget atomic (no dependent read in the tail)
-                if (a.pieces_mode == 1) atomicMax(dst, v);
-                else if (v > *dst) atomicMax(dst, v);
+                // mode 1: the merged interior maximum may land in ANY of the four interior classes — every stride-1 consumer takes
+                // the max over all four — so workgroups spread over them: same-address global atomics serialise in L2 (~50 ns
+                // each: 552 workgroups on one slot row lengthen the kernel's tail by tens of microseconds). Fire-and-forget,
+                // no dependent read.
+                if (a.pieces_mode == 1) {
+                    const int alt[4] = {10, 11, 14, 15};
+                    const int pc2 = pc == 10 ? alt[blockIdx.x & 3] : pc;
+                    atomicMax(reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc2 * a.pieces_ld + a.out_coff + oc, v);
+                } else if (v > *dst) atomicMax(dst, v);
             }
         }
     }
