@@ -4,3 +4,29 @@ The directory name follows the project naming scheme and is not a valid Python i
 package through the top-level alias module `amdq3d` (repo root), which points here.
 """
 __version__ = "0.1.0"
+
+import os as _os
+import sys as _sys
+
+# ROCm 7.2's hipGraph "packet capture" fast path (pre-built AQL packets + kernel-argument blocks made at instantiation)
+# keeps those argument blocks in memory that later hipMalloc calls hand out again: any allocation + write after a capture
+# (a second device plan, a user tensor) silently corrupts the arguments of the captured kernels — wrong detections, or a
+# multi-second stall (measured, reproducible, scratch/dbg_async5.py). The flag below selects the runtime's ordinary
+# per-node graph launch, which is unaffected and measured equally fast for this workload (359 vs 359 frames/s). The HIP
+# runtime reads it once, at its first call, so it has to be in the environment before CUDA is initialised; when that is
+# already too late, GRAPH_REPLAY_SAFE is False and the engine launches eagerly instead of replaying graphs.
+_FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+
+
+def _guard_graph_replay():
+    v = _os.environ.get(_FLAG)
+    if v is not None:
+        return v == "0"
+    torch = _sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_initialized():
+        return False
+    _os.environ[_FLAG] = "0"
+    return True
+
+
+GRAPH_REPLAY_SAFE = _guard_graph_replay()

@@ -36,8 +36,9 @@ class Detector3DTemplate(nn.Module):
                                 "point_head", "roi_head"]
         self._engine = None
         self._extra_engines = []         # forward_async: further device plans, each on its own HIP stream (see async_streams)
+        self._main_stream = None
+        self._ev_prev_main = None
         self._rr = 0
-        import os
         self.async_streams = int(os.environ.get("AQ3D_STREAMS", "1"))   # frames that execute concurrently under forward_async
         self.max_batch_size = 1          # engine buffers are sized for this many frames per forward
         self.voxel_capacity = None       # rows of the sparse buffers (default MAX_NUMBER_OF_VOXELS * max_batch_size)
@@ -193,15 +194,25 @@ class Detector3DTemplate(nn.Module):
         return self._engine
 
     def _async_engine(self):
-        """Round-robin over async_streams device plans. Plan 0 is engine() (it keeps running on the caller's stream); the
-        others own their buffers and a HIP stream each, so that the latency-bound head and tail of one frame (voxelizer,
-        rulebook, small level-0 convs ... decode, NMS) execute beside the heavy middle of another."""
+        """Round-robin over the device plans of forward_async. A split plan (CenterPoint) gets two of them by default, each
+        with its own buffers and index-phase stream: the index phase of frame N+1 (voxelizer + rulebook, latency-bound, on the
+        critical path at the head of a frame) runs beside the dense phase of frame N; the main phases are chained by events, so
+        the heavy kernels of different frames never contend (running whole frames concurrently measured slower)."""
         primary = self.engine()
-        n = max(1, int(self.async_streams))
+        n = max(1, int(self.async_streams)) if not primary.split_index else max(2, int(self.async_streams))
+        if os.environ.get("AQ3D_SPLIT_INDEX", "1") == "0":
+            n = max(1, int(self.async_streams))
+        if os.environ.get("AQ3D_ASYNC_ENGINES"):
+            n = max(1, int(os.environ["AQ3D_ASYNC_ENGINES"]))
         while len(self._extra_engines) < n - 1:
-            e = Engine(self, primary.device)
-            e.stream = torch.cuda.Stream(device=primary.device)
-            self._extra_engines.append(e)
+            self._extra_engines.append(Engine(self, primary.device))
+        for e in [primary] + self._extra_engines:
+            if getattr(e, "stream", None) is None:
+                e.stream = torch.cuda.Stream(device=primary.device)        # index phase (split plans) / whole frame (others)
+                e.main_stream = torch.cuda.Stream(device=primary.device)
+                e.ev_in, e.ev_idx, e.ev_free = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        if self._main_stream is None:
+            self._main_stream = torch.cuda.Stream(device=primary.device)
         k = self._rr % n
         self._rr += 1
         return primary if k == 0 else self._extra_engines[k - 1]
@@ -240,6 +251,13 @@ class CenterPoint(Detector3DTemplate):
         if B > self.max_batch_size:
             self.max_batch_size = B
         eng = self.engine()
+        if self._main_stream is not None:       # frames still in flight from forward_async use this plan's buffers
+            cur = torch.cuda.current_stream(eng.device)
+            cur.wait_stream(self._main_stream)
+            for e in [eng] + self._extra_engines:
+                if getattr(e, "stream", None) is not None:
+                    cur.wait_stream(e.stream)
+                    cur.wait_stream(e.main_stream)
         eng.run(batch_dict)
         batch_dict["final_box_dicts"] = eng.collect(B)
         return self.post_processing(batch_dict)
@@ -253,12 +271,27 @@ class CenterPoint(Detector3DTemplate):
         if B > self.max_batch_size:
             self.max_batch_size = B
         eng = self._async_engine()
-        side = getattr(eng, "stream", None)
-        if side is None:
-            eng.run(batch_dict)
+        caller = torch.cuda.current_stream(eng.device)
+        eng.ev_in.record(caller)                                   # the inputs were produced on the caller's stream
+        if eng.split_index:
+            Bf = eng.begin(batch_dict)
+            eng.stream.wait_event(eng.ev_in)
+            eng.stream.wait_event(eng.ev_free)                     # this plan's previous frame is done with its index buffers
+            with torch.cuda.stream(eng.stream):
+                eng.run_index(batch_dict, Bf)
+                eng.ev_idx.record(eng.stream)
+            # main phases run one after the other, each on its own plan's main stream, chained by events
+            ms = eng.main_stream
+            ms.wait_event(eng.ev_idx)
+            if self._ev_prev_main is not None:
+                ms.wait_event(self._ev_prev_main)
+            with torch.cuda.stream(ms):
+                eng.run_main(Bf)
+                eng.ev_free.record(ms)
+            self._ev_prev_main = eng.ev_free
         else:
-            side.wait_stream(torch.cuda.current_stream(eng.device))     # the inputs were produced on the caller's stream
-            with torch.cuda.stream(side):
+            eng.stream.wait_event(eng.ev_in)
+            with torch.cuda.stream(eng.stream):
                 eng.run(batch_dict)
         return PendingFrame(self, eng, eng.slot, B, batch_dict)
 

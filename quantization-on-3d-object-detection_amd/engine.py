@@ -17,6 +17,12 @@ import torch.nn as nn
 
 from . import ops
 from .modules import SparseBasicBlock, SparseConvolution, SparseSequential, VoxelResBackBone8xVoxelNeXt
+def _graph_replay_safe():
+    import sys
+    pkg = sys.modules.get(__name__.rsplit(".", 1)[0])
+    return bool(getattr(pkg, "GRAPH_REPLAY_SAFE", False))
+
+
 from .quant import QConv2d, QConvNd, QuantConv2d, SQConv2d, _QuantConv2dBase, quantize_weight_rows, surgery_epoch
 
 f32, i32 = torch.float32, torch.int32
@@ -140,14 +146,28 @@ class Engine:
             self._build_sparse(det.backbone_3d)
             self._build_dense(det.backbone_2d, det.dense_head)
         self.arena.finalize()
+        # split plan: the index chain (incl. the voxelizer) is a phase of its own that forward_async runs a frame ahead on a
+        # second stream; VoxelNeXt's bev_merge makes later index steps depend on features, so its plan stays in one piece
+        self.split_index = (not self.fully_sparse) and os.environ.get("AQ3D_SPLIT_INDEX", "1") != "0"
+        self.index_steps = [st for st in self.steps if st[0] in self.INDEX_KINDS] if self.split_index else []
+        self.main_steps = [st for st in self.steps if st[0] not in self.INDEX_KINDS] if self.split_index else list(self.steps)
+        self._graph_now = self._warm_now = False
+        self._index_batch = self._static_batch = None
         self.slot = 0
         self.use_graph = device.type == "cuda" and os.environ.get("AQ3D_GRAPH", "1") != "0"
+        if self.use_graph and not _graph_replay_safe():
+            import warnings
+            warnings.warn("CUDA was initialised before this package was imported and DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 is not set: "
+                          "hipGraph replay is off (ROCm's packet-capture graph path corrupts captured kernel arguments once "
+                          "memory is allocated after a capture); frames are launched eagerly, about 2x slower. Import the "
+                          "package before the first CUDA call or export DEBUG_CLR_GRAPH_PACKET_CAPTURE=0.")
+            self.use_graph = False
         self._graphs, self._pts_buf, self._pts_n, self._warm, self._calibrating = {}, None, 0, 0, None
         self.host_counts = torch.zeros(tuple(self.det_counts.shape), dtype=i32).pin_memory() if device.type == "cuda" else None
         self._ev_done = [torch.cuda.Event() for _ in range(self.NSLOT)] if device.type == "cuda" else None
         # second HIP stream for the index (rulebook) chain, see _run_steps; AQ3D_INDEX_STREAM=0 keeps everything on one stream
         self.index_stream = None
-        if device.type == "cuda" and os.environ.get("AQ3D_INDEX_STREAM", "1") != "0":
+        if device.type == "cuda" and os.environ.get("AQ3D_INDEX_STREAM", "1") != "0" and not self.split_index:
             self.index_stream = torch.cuda.Stream(device=device)
             self._ev_main = torch.cuda.Event()
             self._ev_idx = [torch.cuda.Event() for _ in range(16)]
@@ -935,32 +955,83 @@ class Engine:
         return B
 
     def run(self, batch_dict):
-        """Enqueue one batch. Returns nothing; results sit in self.heads[*]['out_*'] and self.det_counts (slot self.slot).
-        Single-sample frames given as raw points replay a captured hipGraph of the whole frame (one host call instead of
-        ~180 launches: the eager path is host-bound at ~18 us per Python launch); everything else is enqueued eagerly."""
+        """Enqueue one batch on the current stream (index phase, then main phase). Results sit in self.heads[*]['out_*'] and
+        self.det_counts (slot self.slot). Detector.forward_async drives the two phases on different streams instead."""
+        B = self.begin(batch_dict)
+        self.run_index(batch_dict, B)
+        self.run_main(B)
+        return B
+
+    def begin(self, batch_dict):
+        """Per-frame bookkeeping: picks the result slot and whether this frame replays captured hipGraphs (single-sample
+        frames given as raw points: one host call per phase instead of ~180 launches — the eager path is host-bound at
+        ~18 us per Python launch) or is enqueued eagerly (timers, calibration, batches, pre-voxelized input)."""
         B = int(batch_dict["batch_size"])
         if B > self.batch_cap:
             raise ValueError("batch_size %d exceeds the engine's max_batch_size %d" % (B, self.batch_cap))
         self.slot = (self.slot + 1) % self.NSLOT
-        if self._graph_ok(batch_dict, B):
+        self._graph_now = self._graph_ok(batch_dict, B)
+        self._warm_now = self._graph_now and self._warm < 1     # first frame: eager, settles workspaces / kernel attributes
+        if self._warm_now:
+            self._warm += 1
+        return B
+
+    def run_index(self, batch_dict, B):
+        """Phase 1 — everything that depends on the point coordinates only: voxelizer + the whole index chain (hash tables,
+        gather tables, strided output sets). In a split plan it runs on its own stream one frame AHEAD of phase 2."""
+        if self._graph_now:
+            batch_dict = self._stage_points(batch_dict)
+            self._static_batch = batch_dict
+        if not self.split_index:
+            self._index_batch = batch_dict      # un-split plans (VoxelNeXt: bev_merge feeds later index steps) voxelize in phase 2
+            return
+        self._phase("idx", lambda: self._enqueue_index(batch_dict, B))
+
+    def run_main(self, B):
+        """Phase 2 — features: sparse convs, BEV backbone, head, decode, NMS; then the stream-ordered result read-back."""
+        if self.split_index:
+            self._phase(("main", self.slot), lambda: self._enqueue_main(B))
+        else:
+            bd = self._index_batch
+            self._phase(("all", self.slot), lambda: self._enqueue(bd, B))
+        self._publish()
+
+    def _phase(self, key, enqueue):
+        if self._graph_now and not self._warm_now and self.use_graph:
             try:
-                self._run_graph(batch_dict)
-                self._publish()
-                return B
+                g = self._graphs.get(key)
+                if g is None:
+                    torch.cuda.synchronize(self.device)
+                    g = torch.cuda.CUDAGraph()
+                    cur = torch.cuda.current_stream(self.device)
+                    cap = None if cur == torch.cuda.default_stream(self.device) else cur     # the legacy default stream cannot capture
+                    with torch.cuda.graph(g, stream=cap):
+                        enqueue()
+                    self._graphs[key] = g
+                g.replay()
+                return
             except Exception as e:      # capture is an optimisation: fall back to eager launches, once, loudly
                 import warnings
                 warnings.warn("hipGraph capture failed (%r); this engine continues with eager launches" % (e,))
                 self.use_graph = False
                 self._graphs = {}
-        self._enqueue(batch_dict, B)
-        self._publish()
-        return B
+        enqueue()
 
     def _enqueue(self, batch_dict, B):
         self.arena.clear()
         with _Timed(self, "voxelize"):
             self._voxelize(batch_dict, B)
         self._run_steps(self.steps, B)
+
+    def _enqueue_index(self, batch_dict, B):
+        with _Timed(self, "voxelize"):
+            self._voxelize(batch_dict, B)
+        for kind, arg in self.index_steps:
+            self._run_index(kind, arg)
+
+    def _enqueue_main(self, B):
+        self.arena.clear()
+        self._run_steps(self.main_steps, B)
 
     # ------------------------------------------------------------------ hipGraph replay
     def _graph_ok(self, batch_dict, B):
@@ -976,9 +1047,9 @@ class Engine:
         pts = batch_dict["points"]
         return pts.is_cuda and pts.dtype == f32 and pts.dim() == 2
 
-    def _run_graph(self, batch_dict):
-        """Static input buffer (capacity rounded up, tail rows parked outside the point-cloud range so the voxelizer drops
-        them — first-touch order and therefore every index stays bit-identical to the eager path) + one graph per slot."""
+    def _stage_points(self, batch_dict):
+        """Static input buffer of the captured graphs (capacity rounded up, tail rows parked outside the point-cloud range so
+        the voxelizer drops them — first-touch order and therefore every index stays bit-identical to the eager path)."""
         pts = batch_dict["points"]
         n, stride = int(pts.shape[0]), int(pts.shape[1])
         buf = self._pts_buf
@@ -996,19 +1067,7 @@ class Engine:
         if self._pts_n > n:
             buf[n:self._pts_n] = self._pts_far
         self._pts_n = n
-        g = self._graphs.get(self.slot)
-        if g is None:
-            static = {"points": buf, "batch_size": 1}
-            if self._warm < 1:      # first frame: eager, settles workspaces and kernel attributes before any capture
-                self._warm += 1
-                self._enqueue(static, 1)
-                return
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._enqueue(static, 1)
-            self._graphs[self.slot] = g
-        g.replay()
+        return {"points": buf, "batch_size": 1}
 
     def _publish(self):
         """Detection counts of this frame → pinned host memory, stream-ordered, plus an event: collect() waits for THIS frame
@@ -1025,7 +1084,8 @@ class Engine:
         events: the index stream waits for whatever the main stream produced for it (voxelizer, bev_merge), the main stream
         waits for the newest index event before the next kernel that might read a gather table."""
         main = torch.cuda.current_stream(self.device)
-        side = self.index_stream
+        # no fork without index steps (main phase of a split plan): an un-joined side stream must not enter a capture
+        side = self.index_stream if any(k in self.INDEX_KINDS for k, _ in steps) else None
         pending = None        # newest event recorded on the index stream that main has not waited for yet
         if side is not None:
             self._ev_main.record(main)      # everything enqueued so far on main (voxelizer / arena clear)

@@ -70,6 +70,43 @@ def test_graph_replay_and_two_frames_in_flight_match_eager(dev):
     assert int(c0.sum()) == len(ref[0][1]) and _same(ref[0], r0) and _same(ref[2], r1)
 
 
+def test_graph_replay_survives_later_allocations_and_a_second_plan(dev):
+    """Regression for ROCm's graph packet-capture path (see the package __init__): memory allocated and written AFTER a capture
+    must not change what a replay computes. Also the pipelined forward_async (two plans, index phase one frame ahead)."""
+    import amdq3d
+    assert amdq3d.GRAPH_REPLAY_SAFE and os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
+    ds, model = _model()
+    eng = model.engine()
+    eng.use_graph = False
+    with torch.no_grad():
+        ref = [_np(model(_batch(ds, i % 2, dev))[0][0]) for i in range(2)]
+    eng.use_graph = True
+    with torch.no_grad():
+        for _ in range(3):
+            got = [_np(model(_batch(ds, i, dev))[0][0]) for i in range(2)]
+    assert len(eng._graphs) >= 2 and all(_same(r, g) for r, g in zip(ref, got))
+    junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(64)]
+    junk += [torch.full((1 << 12,), float("nan"), device=dev) for _ in range(4000)]
+    junk += [torch.full((16,), float("nan"), device=dev) for _ in range(4000)]
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        got = [_np(model(_batch(ds, i, dev))[0][0]) for i in range(2)]
+    assert all(_same(r, g) for r, g in zip(ref, got))
+    # pipelined: frame N+1 is enqueued (its index phase runs on the second plan's stream) before frame N is read back
+    with torch.no_grad():
+        pend, outs = None, []
+        for i in range(9):
+            cur = model.forward_async(_batch(ds, i % 2, dev))
+            if pend is not None:
+                outs.append(_np(pend.result()[0][0]))
+            pend = cur
+        outs.append(_np(pend.result()[0][0]))
+    assert len(model._extra_engines) == 1 and all("idx" in e._graphs for e in [model._engine] + model._extra_engines)
+    for i, o in enumerate(outs):
+        assert _same(ref[i % 2], o), "pipelined frame %d differs" % i
+    del junk
+
+
 @pytest.mark.parametrize("env", ["AQ3D_NO_GROUPS", "AQ3D_INDEX_STREAM"])
 def test_grouped_launches_and_index_stream_do_not_change_results(dev, env, monkeypatch):
     """nuScenes 6-head model: 36 first convs + 36 final convs go out as grouped launches; the rulebook runs on its own stream."""
