@@ -230,67 +230,111 @@ __global__ __launch_bounds__(256) void sq_weights_kernel(SqGroup grp, int K, flo
     if (threadIdx.x == 0) q.out_mul[oc] = __fmul_rn(inv_sx, __fdiv_rn(1.0f, dv));
 }
 
-// Fused form of the two kernels above, one launch per layer: every block (= one output channel) recomputes the K smoothing
-// scales from the 16 x Cin piece maxima (8 KB, L2-resident: ~20 flops per column, cheaper than a dependent second launch),
-// keeps them in LDS, derives the per-tensor activation amax max_j a_j / s_j redundantly, then quantises its weight row.
-// Block 0 publishes s, 1/s, the activation scale and the amax (calibration harvest reads it back).
-__global__ __launch_bounds__(256) void sq_prep_fused_kernel(const float *__restrict__ pieces, const float *__restrict__ w_colmax,
-                                                            const float *__restrict__ weight, int Cin, int ntaps, TapMasks tm,
-                                                            float alpha, float qmax_w, const float *__restrict__ static_amax_w,
-                                                            float static_amax_x, float qmax_a, float *__restrict__ s_out,
-                                                            float *__restrict__ r_out, float *__restrict__ amax_x_acc,
-                                                            float *__restrict__ scal, int8_t *__restrict__ wq,
-                                                            float *__restrict__ out_mul, float *__restrict__ amax_w_out) {
-    extern __shared__ float s_lds[];        // [K]
-    __shared__ float sh[16];
-    const int K = Cin * ntaps;
-    const int oc = blockIdx.x;
-    const float eps = 1.0f / (float)(1 << 24);
-    float t = 0.f;
-    for (int j = threadIdx.x; j < K; j += 256) {
-        const int tap = j / Cin, c = j - tap * Cin;
-        const unsigned mask = tm.m[tap];
-        float a = 0.f;
-#pragma unroll
-        for (int p = 0; p < 16; ++p)
-            if (mask & (1u << p)) a = fmaxf(a, pieces[p * Cin + c]);
-        float s = 1.f;
-        if (alpha >= 0.f) {
-            const float w = w_colmax[j];
-            if (alpha == 0.5f) s = __fdiv_rn(sqrtf(a), sqrtf(w));
-            else s = __fdiv_rn(powf(a, alpha), powf(w, 1.f - alpha));
-            if (s == 0.f) s = 1.f;
-        }
-        s_lds[j] = s;
-        if (oc == 0) {
-            s_out[j] = s;
-            r_out[j] = __fdiv_rn(1.0f, s);
-        }
-        t = fmaxf(t, fabsf(__fdiv_rn(a, s)));
+// Fused form of the two kernels above: ONE launch per layer group instead of two dependent ones (each dependent launch in a
+// captured frame costs its run time plus ~6 us of dispatch gap, 14 layers per frame). One block per output channel, as in
+// sq_weights_kernel. A thread owns up to SQ_V groups of four consecutive columns (same tap, Cin % 4 == 0): its weight and
+// w_colmax quads are requested first, so that their latency overlaps the one coalesced round trip that stages the 16 x Cin
+// piece maxima in LDS; the smoothing scales of its columns are then computed in registers (redundantly across blocks, but
+// concurrently), and the weight row is quantised from registers — one global round trip in all. Block x == 0 publishes s, 1/s,
+// the activation scale and the amax. Same arithmetic, same results as the two-kernel path.
+#define SQ_FUSED_THREADS 512
+#define SQ_V 3
+__device__ __forceinline__ float sq_scale_of(float a, float w, float alpha) {
+    float s = 1.f;
+    if (alpha >= 0.f) {
+        // torch.pow(x, 0.5) takes the sqrt path; other exponents go through powf
+        if (alpha == 0.5f) s = __fdiv_rn(sqrtf(a), sqrtf(w));
+        else s = __fdiv_rn(powf(a, alpha), powf(w, 1.f - alpha));
+        if (s == 0.f) s = 1.f;
     }
-    const float amax_dyn = block_max_1024(t, sh);       // also orders the s_lds writes before the reads below
-    const float amax_x = static_amax_x > 0.f ? static_amax_x : amax_dyn;
+    return s;
+}
+__device__ __forceinline__ signed char sq_code(float w, float s, float sw, float qmax) {
+    return (signed char)(int)fminf(fmaxf(rintf(__fmul_rn(__fmul_rn(w, s), sw)), -qmax - 1.f), qmax);
+}
+__global__ __launch_bounds__(SQ_FUSED_THREADS) void sq_prep_row_kernel(SqGroup grp, int Cin, int ntaps, TapMasks tm, float qmax_w,
+                                                                       float qmax_a) {
+    const SqOne q = grp.p[blockIdx.y];
+    const int oc = blockIdx.x;
+    if (oc >= q.Cout) return;
+    extern __shared__ float4 p_lds[];       // [16][Cin/4]
+    __shared__ float sh[16];
+    const int K4 = (Cin * ntaps) >> 2, C4 = Cin >> 2;
+    const float eps = 1.0f / (float)(1 << 24);
+    const bool pub = oc == 0;
+    const float4 *wrow = reinterpret_cast<const float4 *>(q.weight + (size_t)oc * K4 * 4);
+    const float4 *wcm = reinterpret_cast<const float4 *>(q.w_colmax);
+    float4 w[SQ_V], wc[SQ_V], sv[SQ_V];
+#pragma unroll
+    for (int i = 0; i < SQ_V; ++i) {
+        const int g = threadIdx.x + i * SQ_FUSED_THREADS;
+        w[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        wc[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (g < K4) {
+            w[i] = wrow[g];
+            if (q.alpha >= 0.f) wc[i] = wcm[g];
+        }
+    }
+    for (int i = threadIdx.x; i < 16 * C4; i += SQ_FUSED_THREADS) p_lds[i] = reinterpret_cast<const float4 *>(q.pieces)[i];
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < SQ_V; ++i) {
+        const int g = threadIdx.x + i * SQ_FUSED_THREADS;
+        sv[i] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (g < K4) {
+            const int tap = g / C4, c4 = g - tap * C4;
+            const unsigned mask = tm.m[tap];
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                if (mask & (1u << p)) {     // uniform per tap; at most one tap boundary inside a wave
+                    const float4 v = p_lds[p * C4 + c4];
+                    a.x = fmaxf(a.x, v.x); a.y = fmaxf(a.y, v.y); a.z = fmaxf(a.z, v.z); a.w = fmaxf(a.w, v.w);
+                }
+            }
+            float4 sc;
+            sc.x = sq_scale_of(a.x, wc[i].x, q.alpha); sc.y = sq_scale_of(a.y, wc[i].y, q.alpha);
+            sc.z = sq_scale_of(a.z, wc[i].z, q.alpha); sc.w = sq_scale_of(a.w, wc[i].w, q.alpha);
+            sv[i] = sc;
+            if (pub) {
+                reinterpret_cast<float4 *>(q.s)[g] = sc;
+                reinterpret_cast<float4 *>(q.r)[g] = make_float4(__fdiv_rn(1.0f, sc.x), __fdiv_rn(1.0f, sc.y), __fdiv_rn(1.0f, sc.z),
+                                                                 __fdiv_rn(1.0f, sc.w));
+            }
+            t = fmaxf(fmaxf(t, fabsf(__fdiv_rn(a.x, sc.x))), fabsf(__fdiv_rn(a.y, sc.y)));
+            t = fmaxf(fmaxf(t, fabsf(__fdiv_rn(a.z, sc.z))), fabsf(__fdiv_rn(a.w, sc.w)));
+        }
+    }
+    const float amax_dyn = block_max_1024(t, sh);
+    const float amax_x = q.static_amax_x > 0.f ? q.static_amax_x : amax_dyn;
     float sx = __fdiv_rn(qmax_a, amax_x), dvx = sx;
     if (amax_x <= eps) { sx = 0.f; dvx = 1.f; }
     const float inv_sx = __fdiv_rn(1.0f, dvx);
-    if (oc == 0 && threadIdx.x == 0) {
-        scal[0] = sx; scal[1] = amax_x; scal[2] = inv_sx; scal[3] = static_amax_x > 0.f ? 1.f : 0.f;
-        if (amax_dyn > 0.f && amax_dyn > *amax_x_acc) aq3d_atomic_max_pos(amax_x_acc, amax_dyn);
+    if (pub && threadIdx.x == 0) {
+        q.scal[0] = sx; q.scal[1] = amax_x; q.scal[2] = inv_sx; q.scal[3] = q.static_amax_x > 0.f ? 1.f : 0.f;
+        if (amax_dyn > 0.f && amax_dyn > *q.amax_x_acc) aq3d_atomic_max_pos(q.amax_x_acc, amax_dyn);
     }
-    const float *wrow = weight + (size_t)oc * K;
     float mx = 0.f;
-    for (int j = threadIdx.x; j < K; j += 256) mx = fmaxf(mx, fabsf(__fmul_rn(wrow[j], s_lds[j])));
+#pragma unroll
+    for (int i = 0; i < SQ_V; ++i) {        // absent groups hold w = 0
+        mx = fmaxf(fmaxf(mx, fabsf(__fmul_rn(w[i].x, sv[i].x))), fabsf(__fmul_rn(w[i].y, sv[i].y)));
+        mx = fmaxf(fmaxf(mx, fabsf(__fmul_rn(w[i].z, sv[i].z))), fabsf(__fmul_rn(w[i].w, sv[i].w)));
+    }
     float amax = block_max_1024(mx, sh);
-    if (threadIdx.x == 0) amax_w_out[oc] = amax;
-    if (static_amax_w) amax = static_amax_w[oc];
+    if (threadIdx.x == 0) q.amax_w_out[oc] = amax;   // dynamic per-oc amax of W*s (what a max calibrator collects)
+    if (q.static_amax_w) amax = q.static_amax_w[oc];
     float sw = __fdiv_rn(qmax_w, amax), dv = sw;
     if (amax <= eps) { sw = 0.f; dv = 1.f; }
-    for (int j = threadIdx.x; j < K; j += 256) {
-        float q = rintf(__fmul_rn(__fmul_rn(wrow[j], s_lds[j]), sw));
-        q = fminf(fmaxf(q, -qmax_w - 1.f), qmax_w);
-        wq[(size_t)oc * K + j] = (int8_t)(int)q;
+    char4 *dst = reinterpret_cast<char4 *>(q.wq + (size_t)oc * K4 * 4);
+#pragma unroll
+    for (int i = 0; i < SQ_V; ++i) {
+        const int g = threadIdx.x + i * SQ_FUSED_THREADS;
+        if (g < K4)
+            dst[g] = make_char4(sq_code(w[i].x, sv[i].x, sw, qmax_w), sq_code(w[i].y, sv[i].y, sw, qmax_w),
+                                sq_code(w[i].z, sv[i].z, sw, qmax_w), sq_code(w[i].w, sv[i].w, sw, qmax_w));
     }
-    if (threadIdx.x == 0) out_mul[oc] = __fmul_rn(inv_sx, __fdiv_rn(1.0f, dv));
+    if (threadIdx.x == 0) q.out_mul[oc] = __fmul_rn(inv_sx, __fdiv_rn(1.0f, dv));
 }
 
 extern "C" int aq3d_sq_prep_group(const aq3d_sq_prep_problem *probs, int32_t n, int32_t w_bits, int32_t a_bits, void *stream_) {
@@ -309,7 +353,6 @@ extern "C" int aq3d_sq_prep_group(const aq3d_sq_prep_problem *probs, int32_t n, 
     }
     SqGroup grp;
     int max_cout = 0;
-    bool fused_ok = n == 1;
     for (int i = 0; i < n; ++i) {
         const aq3d_sq_prep_problem &q = probs[i];
         AQ3D_REQUIRE(q.pieces && q.weight && q.geom && q.params && q.amax_x_acc, "aq3d_sq_prep: null argument");
@@ -328,14 +371,12 @@ extern "C" int aq3d_sq_prep_group(const aq3d_sq_prep_problem *probs, int32_t n, 
     for (int i = n; i < AQ3D_SQ_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     const int ntaps = g->ksize * g->ksize, K = g->Cin * ntaps;
     const float qa = (float)((1 << (a_bits - 1)) - 1), qw = (float)((1 << (w_bits - 1)) - 1);
-    // measured: the fused single launch is SLOWER than the two small ones (13.6-28 us vs 14-16 us per layer; every block
-    // redoes 16 x K piece reads), so it stays an experiment
-    static const bool fused = getenv("AQ3D_SQ_PREP_FUSED") != nullptr;
-    if (fused && fused_ok && (size_t)K * 4 <= 60 * 1024) {
-        const SqOne &o = grp.p[0];
-        hipLaunchKernelGGL(sq_prep_fused_kernel, dim3(o.Cout), dim3(256), (size_t)K * 4, stream, o.pieces, o.w_colmax, o.weight, g->Cin,
-                           ntaps, tm, o.alpha, qw, o.static_amax_w, o.static_amax_x, qa, o.s, o.r, o.amax_x_acc, o.scal, o.wq, o.out_mul,
-                           o.amax_w_out);
+    // AQ3D_SQ_PREP_FUSED=0 selects the two-kernel path (scales, then one block per output channel)
+    static const bool fused = !(getenv("AQ3D_SQ_PREP_FUSED") && atoi(getenv("AQ3D_SQ_PREP_FUSED")) == 0);
+    const size_t lds_bytes = 16 * (size_t)g->Cin * 4;
+    if (fused && (g->Cin & 3) == 0 && K <= 4 * SQ_V * SQ_FUSED_THREADS && lds_bytes <= 60 * 1024) {
+        hipLaunchKernelGGL(sq_prep_row_kernel, dim3(max_cout, n), dim3(SQ_FUSED_THREADS), lds_bytes, stream, grp, g->Cin, ntaps, tm,
+                           qw, qa);
         AQ3D_CHECK_LAUNCH("aq3d_sq_prep");
         return AQ3D_OK;
     }
