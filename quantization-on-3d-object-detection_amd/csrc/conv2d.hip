@@ -751,6 +751,9 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvGroup grp) {
     for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < TJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __shared__ unsigned int pm[16 * BM];     // piece maxima of this workgroup's outputs (bit patterns of |v|)
+    if (a.pieces_out)
+        for (int i = tid; i < 16 * BM; i += 256) pm[i] = 0u;      // ordered before its use by the K loop's barriers
 
     auto mma_step = [&](int buf) {
 #pragma unroll
@@ -811,13 +814,25 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(ConvGroup grp) {
                 if (a.relu) t = fmaxf(t, 0.f);
                 a.y[opix * a.out_ld + a.out_coff + oc] = t;
                 if (a.pieces_out) {
+                    // workgroup-level merge in LDS first (a broadcast read filters nearly every element; the global slots took one
+                    // dependent L2 read + atomic per OUTPUT ELEMENT before, which was most of this kernel's run time)
                     const int OW = d > 0 ? a.Wo * d : a.Wo, OH = d > 0 ? a.Ho * d : a.Ho;
                     const int oh = (int)(opix / OW), ow = (int)(opix - (size_t)oh * OW);
-                    unsigned int *dst = reinterpret_cast<unsigned int *>(a.pieces_out) +
-                                        (size_t)(piece_cls(oh, OH) * 4 + piece_cls(ow, OW)) * a.pieces_ld + a.out_coff + oc;
+                    unsigned int *slot = &pm[(piece_cls(oh, OH) * 4 + piece_cls(ow, OW)) * BM + (row - row0)];
                     const unsigned int vb = __float_as_uint(fabsf(t));
-                    if (vb > *dst) atomicMax(dst, vb);
+                    if (vb > *slot) atomicMax(slot, vb);
                 }
+            }
+        }
+    }
+    if (a.pieces_out) {
+        __syncthreads();
+        for (int i = tid; i < 16 * BM; i += 256) {
+            const unsigned int v = pm[i];
+            const int row = row0 + i % BM;
+            if (v != 0u && row < a.rows_total) {
+                const int oc = d > 0 ? row % a.Cout : row;
+                atomicMax(reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)(i / BM) * a.pieces_ld + a.out_coff + oc, v);
             }
         }
     }
