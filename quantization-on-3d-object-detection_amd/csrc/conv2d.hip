@@ -986,6 +986,199 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
     return aq3d_conv2d_i8_group(&q, 1, stream_);
 }
 
+// ------------------------------------------------------------------ fp32 conv on the fp16 matrix pipe (split operands)
+// Same tiling and staging as conv2d_f32_kernel, but the products run as v_mfma_f32_16x16x32_f16: every fp32 operand x is staged in
+// LDS as hi = f16(x) and lo' = f16((x - hi) * 2^11) (x == hi + lo exactly in fp32; lo' carries 11 more bits), and
+//     acc  += hi_w * hi_x            accl += hi_w * lo'_x + lo'_w * hi_x            y = acc + accl * 2^-11
+// with fp32 accumulation. Dropped: the lo*lo term and the rounding of lo', both ~2^-22 relative to the product — the result
+// differs from exact fp32 products by ~5e-7 relative, below the reordering noise of any fp32 GEMM (and far below the TF32 the
+// reference's cuDNN uses for these convolutions on Ampere). 3 MFMAs of 16 cycles per 32-deep K step instead of 8 of 32 cycles:
+// the fp32 matrix pipe (157 TFLOP/s) was what bound the deblocks. |x| must stay below the fp16 range (65504); the exact
+// fp32-pipe kernel above remains available through AQ3D_F32_EXACT=1.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int WM, int WN, int TI, int TJ>
+__global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
+    const ConvArgs a = grp.p[blockIdx.z];
+    if ((int)blockIdx.y * WM * TI * 16 >= a.rows_total) return;
+    constexpr int KS = 32;
+    constexpr int BM = WM * TI * 16;
+    constexpr int BN = WN * TJ * 16;
+    constexpr int LD = 2 * KS + 8;  // halves per LDS row: KS hi | KS lo | 16 B pad
+    constexpr int QPR = KS / 4;     // float4 quads per row and step
+    static_assert(WM * WN == 4, "4 waves");
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (BM + BN) * LD];
+    auto Wbuf = [&](int b) -> _Float16 * { return smem + b * (BM + BN) * LD; };
+    auto Xbuf = [&](int b) -> _Float16 * { return smem + b * (BM + BN) * LD + BM * LD; };
+    constexpr int XI = (BN * QPR + 255) / 256;
+    constexpr int WI = (BM * QPR + 255) / 256;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int L = a.Ho * a.Wo;
+    const int K = a.Cin * a.ks * a.ks;
+    const int pix0 = blockIdx.x * BN;
+    const int row0 = blockIdx.y * BM;
+    const int cchunks = a.Cin / KS;
+    const int nk = a.ks * a.ks * cchunks;
+
+    int ph[XI], pw[XI];
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int item = tid + 256 * i;
+        const int p = pix0 + item / QPR;
+        if (item / QPR < BN && p < L) {
+            int ho = p / a.Wo;
+            ph[i] = ho * a.stride - a.pad;
+            pw[i] = (p - ho * a.Wo) * a.stride - a.pad;
+        } else {
+            ph[i] = -0x10000;
+            pw[i] = -0x10000;
+        }
+    }
+    f32x4 xr[XI], wr[WI];
+    auto load_step = [&](int kstep) {
+        const int tap = kstep / cchunks, c0 = (kstep - tap * cchunks) * KS;
+        const int kh = tap / a.ks, kw = tap - kh * a.ks;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int item = tid + 256 * i;
+            const int hi = ph[i] + kh, wi = pw[i] + kw;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (hi >= 0 && hi < a.H && wi >= 0 && wi < a.W)
+                v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)hi * a.W + wi) * a.in_ld + c0 + (item % QPR) * 4);
+            xr[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int item = tid + 256 * i;
+            const int row = item / QPR;
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (row < BM && row0 + row < a.rows_total)
+                v = *reinterpret_cast<const f32x4 *>(static_cast<const float *>(a.w) + (size_t)(row0 + row) * K +
+                                                      (size_t)tap * a.Cin + c0 + (item % QPR) * 4);
+            wr[i] = v;
+        }
+    };
+    auto put_split = [&](_Float16 *row, int q, f32x4 v) {
+        f16x4 h, l;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            h[r] = (_Float16)v[r];
+            l[r] = (_Float16)__fmul_rn(__fsub_rn(v[r], (float)h[r]), 2048.f);
+        }
+        *reinterpret_cast<f16x4 *>(row + q * 4) = h;
+        *reinterpret_cast<f16x4 *>(row + KS + q * 4) = l;
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int item = tid + 256 * i;
+            if (item / QPR < BN) put_split(Xbuf(buf) + (item / QPR) * LD, item % QPR, xr[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int item = tid + 256 * i;
+            if (item / QPR < BM) put_split(Wbuf(buf) + (item / QPR) * LD, item % QPR, wr[i]);
+        }
+    };
+
+    f32x4 acc[TI][TJ], accl[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            accl[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    __shared__ unsigned int pm[16 * BM];     // piece maxima of this workgroup's outputs (bit patterns of |v|)
+    if (a.pieces_out)
+        for (int i = tid; i < 16 * BM; i += 256) pm[i] = 0u;      // ordered before its use by the K loop's barriers
+
+    auto mma_step = [&](int buf) {
+        f16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const _Float16 *r = Wbuf(buf) + (wm * TI * 16 + i * 16 + l15) * LD + g * 8;
+            ah[i] = *reinterpret_cast<const f16x8 *>(r);
+            al[i] = *reinterpret_cast<const f16x8 *>(r + KS);
+        }
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const _Float16 *r = Xbuf(buf) + (wn * TJ * 16 + j * 16 + l15) * LD + g * 8;
+            bh[j] = *reinterpret_cast<const f16x8 *>(r);
+            bl[j] = *reinterpret_cast<const f16x8 *>(r + KS);
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                accl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accl[i][j], 0, 0, 0);
+                accl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accl[i][j], 0, 0, 0);
+            }
+    };
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int k = 0; k + 1 < nk; ++k) {       // branch-free steady state, last step peeled (see conv2d_i8_kernel)
+        const int buf = k & 1;
+        load_step(k + 1);
+        mma_step(buf);
+        store_step(buf ^ 1);
+        __syncthreads();
+    }
+    mma_step((nk - 1) & 1);
+
+    const int d = a.deconv;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int rbase = row0 + wm * TI * 16 + i * 16 + 4 * g;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int p = pix0 + wn * TJ * 16 + j * 16 + l15;
+            if (p >= L) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rbase + r;
+                if (row >= a.rows_total) continue;
+                int oc = row;
+                size_t opix = (size_t)p;
+                if (d > 0) {  // row = (i*d + j)*Cout + oc ; input pixel p = (h, w) → output (h*d+i, w*d+j)
+                    const int ij = row / a.Cout;
+                    oc = row - ij * a.Cout;
+                    const int h = p / a.Wo, w = p - h * a.Wo;
+                    opix = (size_t)(h * d + ij / d) * (a.Wo * d) + (w * d + ij % d);
+                }
+                float t = __fadd_rn(acc[i][j][r], __fmul_rn(accl[i][j][r], 1.0f / 2048.f));
+                if (a.bias) t = __fadd_rn(t, a.bias[oc]);
+                if (a.post_scale) t = __fadd_rn(__fmul_rn(t, a.post_scale[oc]), a.post_shift[oc]);
+                if (a.relu) t = fmaxf(t, 0.f);
+                a.y[opix * a.out_ld + a.out_coff + oc] = t;
+                if (a.pieces_out) {
+                    const int OW = d > 0 ? a.Wo * d : a.Wo, OH = d > 0 ? a.Ho * d : a.Ho;
+                    const int oh = (int)(opix / OW), ow = (int)(opix - (size_t)oh * OW);
+                    unsigned int *slot = &pm[(piece_cls(oh, OH) * 4 + piece_cls(ow, OW)) * BM + (row - row0)];
+                    const unsigned int vb = __float_as_uint(fabsf(t));
+                    if (vb > *slot) atomicMax(slot, vb);
+                }
+            }
+        }
+    }
+    if (a.pieces_out) {
+        __syncthreads();
+        for (int i = tid; i < 16 * BM; i += 256) {
+            const unsigned int v = pm[i];
+            const int row = row0 + i % BM;
+            if (v != 0u && row < a.rows_total) {
+                const int oc = d > 0 ? row % a.Cout : row;
+                atomicMax(reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)(i / BM) * a.pieces_ld + a.out_coff + oc, v);
+            }
+        }
+    }
+}
+
 static int prep_f32(ConvArgs *a, const aq3d_conv2d_problem *q, int *L_out) {
     const aq3d_conv2d_geom *g = q->geom;
     int rc = fill_args(a, q->x, g, q->bias, q->post_scale, q->post_shift, q->y, "aq3d_conv2d_f32");
@@ -1028,6 +1221,21 @@ extern "C" int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *probs, int32_t n
         max_rows = grp.p[i].rows_total > max_rows ? grp.p[i].rows_total : max_rows;
     }
     for (int i = n; i < AQ3D_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
+    static const bool exact = getenv("AQ3D_F32_EXACT") && atoi(getenv("AQ3D_F32_EXACT")) != 0;
+    bool split_ok = !exact;
+    for (int i = 0; i < n; ++i) split_ok = split_ok && (probs[i].geom->Cin & 31) == 0;
+    if (split_ok) {     // fp16 matrix pipe, split operands (see conv2d_f16s_kernel)
+        if (cls == 0) hipLaunchKernelGGL((conv2d_f16s_kernel<1, 4, 1, 2>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
+        else if (cls == 1) hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
+        else {
+            static const int c2 = getenv("AQ3D_F16S_CLS2") ? atoi(getenv("AQ3D_F16S_CLS2")) : 0;
+            if (c2 == 0) hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
+            else if (c2 == 1) hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 4, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 128), n), dim3(256), 0, stream, grp);
+            else hipLaunchKernelGGL((conv2d_f32_kernel<2, 2, 4, 2, 16>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 128), n), dim3(256), 0, stream, grp);
+        }
+        AQ3D_CHECK_LAUNCH("aq3d_conv2d_f32");
+        return AQ3D_OK;
+    }
     if (cls == 0) {
         hipLaunchKernelGGL((conv2d_f32_kernel<1, 4, 1, 2, 16>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
     } else if (cls == 1) {
