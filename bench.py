@@ -10,6 +10,7 @@ A step = one pass of the whole hot path (voxelize → sparse backbone → BEV ba
 frame, including the single device→host read of the detection counts that ends Detector.forward.
 """
 import argparse
+import collections
 import json
 import os
 import sys
@@ -130,6 +131,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="centerpoint", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=2, help="frames enqueued before the oldest one is read back")
     ap.add_argument("--breakdown", action="store_true", help="time every kernel family in an extra pass (stderr)")
     args = ap.parse_args()
 
@@ -169,7 +171,7 @@ def main():
 
     # graph warm-up (untimed): the first frames without per-kernel events capture the per-slot hipGraphs the timed region replays
     with torch.no_grad():
-        for i in range(4 * eng.NSLOT):
+        for i in range(4 * eng.NSLOT * max(1, args.inflight)):
             model.forward_async(dict(batches[i % len(batches)])).counts()
     D.barrier()
     torch.cuda.synchronize(dev)
@@ -177,15 +179,14 @@ def main():
     # two frames in flight: frame i+1 is enqueued before the detections of frame i are read back (every frame is still
     # completed and read inside this region)
     n_det = 0
-    prev = None
+    pending = collections.deque()
     for i in range(args.steps):
         with torch.no_grad():
-            cur = model.forward_async(dict(batches[i % len(batches)]))
-        if prev is not None:
-            n_det += int(prev.counts().sum())
-        prev = cur
-    if prev is not None:
-        n_det += int(prev.counts().sum())
+            pending.append(model.forward_async(dict(batches[i % len(batches)])))
+        if len(pending) >= args.inflight:
+            n_det += int(pending.popleft().counts().sum())
+    while pending:
+        n_det += int(pending.popleft().counts().sum())
     torch.cuda.synchronize(dev)
     D.barrier()
     elapsed = time.perf_counter() - t0
@@ -241,7 +242,7 @@ def main():
             "config": {"workload": wl_desc, "frames": N_FRAMES, "points": n_points, "voxels": n_voxels, "parallelism": "replicas(frames)x%d" % world,
                        "avg_boxes_per_frame": n_det / max(args.steps, 1)},
             "roofline": roof,
-            "execution": "hipGraph replay, 2 frames in flight" if getattr(eng, "_graphs", None) else "eager launches, 2 frames in flight",
+            "execution": "%s, %d frames in flight" % ("hipGraph replay" if getattr(eng, "_graphs", None) else "eager launches", args.inflight),
             "warmup_breakdown_ms_per_frame": {k: v[1] / n_warm for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -12,6 +12,7 @@
 // among equal scores is unspecified; we fix it to (score desc, flat index asc) and the oracle does the same.
 #include "common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 typedef unsigned long long u64;
 
@@ -247,12 +248,15 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
                 }
                 if (lane == 63) sh[threadIdx.x >> 6] = incl;
             }
+            // read BEFORE the barrier: the pivot thread below overwrites s_remaining, and a wave that arrives later must not
+            // test against the new value (it could elect a second pivot — seen as one detection more or less, once in a few
+            // hundred frames, when another stream's kernels shared the CU and pulled the four waves apart)
+            const int rem = s_remaining;
             __syncthreads();
             if (threadIdx.x < 256) {
                 int basev = 0;
                 for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) basev += sh[w];
                 incl += basev;                             // keys in bins >= (255 - tid)
-                const int rem = s_remaining;
                 if (incl >= rem && incl - v < rem) {       // exactly one thread
                     s_prefix = prefix | ((unsigned int)(255 - threadIdx.x) << shift);
                     s_remaining = rem - (incl - v);
@@ -518,8 +522,18 @@ __device__ __forceinline__ void box_corners(const float *b, P2 *c) {
     c[4] = c[0];
 }
 
-__device__ float rotated_overlap(const float *ba, const float *bb) {
-    P2 ca[5], cb[5], pts[16];
+// The intersection polygon (<= 16 points, indexed at run time) lives in LDS: pts_lds points at this thread's first element,
+// consecutive points are PTS_STRIDE apart. A per-thread array here would be scratch memory — the only scratch in the whole
+// frame — and this kernel's results turned out to depend on what other HIP streams were running beside it (one detection
+// more or less once in a few hundred frames, inputs bit-identical); with the points in LDS the kernel has no private
+// segment and the effect is gone.
+template <int PTS_STRIDE>
+__device__ float rotated_overlap(const float *ba, const float *bb, P2 *pts_lds) {
+    P2 ca[5], cb[5];
+    struct Pts {
+        P2 *base;
+        __device__ __forceinline__ P2 &operator[](int k) const { return base[k * PTS_STRIDE]; }
+    } pts = {pts_lds};
     box_corners(ba, ca);
     box_corners(bb, cb);
     int cnt = 0;
@@ -552,9 +566,14 @@ __device__ float rotated_overlap(const float *ba, const float *bb) {
     return fabsf(area) / 2.0f;
 }
 
-__device__ __forceinline__ float iou_bev_dev(const float *a, const float *b) {
+template <int PTS_STRIDE>
+__device__ __forceinline__ float iou_bev_dev(const float *a, const float *b, P2 *pts_lds) {
     const float sa = a[3] * a[4], sb = b[3] * b[4];
-    const float ov = rotated_overlap(a, b);
+    // The same BEV rectangle twice (one pixel ranked in two classes: the regression maps are shared) is the degenerate case of
+    // the clipping below — eight coincident corner pairs ordered by angle — where its fan area is decided by last-bit ties
+    // (0.68 or 1.0 came out of the same inputs). The exact overlap of a rectangle with itself is its area.
+    const bool same = a[0] == b[0] && a[1] == b[1] && a[3] == b[3] && a[4] == b[4] && a[6] == b[6];
+    const float ov = same ? sa : rotated_overlap<PTS_STRIDE>(a, b, pts_lds);
     return ov / fmaxf(sa + sb - ov, IOU_EPS);
 }
 
@@ -565,6 +584,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
     if (n > cap) n = cap;
     const int row = blockIdx.x, cb = blockIdx.y;
     if (row >= n) return;
+    __shared__ P2 pts_s[16 * 64];
     const int rb = row >> 6;
     u64 word = 0ull;
     if (cb >= rb) {
@@ -574,7 +594,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
             float a[7], b[7];
 #pragma unroll
             for (int k = 0; k < 7; ++k) { a[k] = boxes[(size_t)row * box_ld + k]; b[k] = boxes[(size_t)j * box_ld + k]; }
-            sup = iou_bev_dev(a, b) > thresh;
+            sup = iou_bev_dev<64>(a, b, pts_s + threadIdx.x) > thresh;
         }
         word = __ballot(sup);
     }
@@ -697,6 +717,7 @@ __global__ __launch_bounds__(256) void boxes_iou3d_kernel(const float *__restric
                                                           const float *__restrict__ B, int m, int ldb,
                                                           float *__restrict__ out) {
     const long long total = (long long)n * m;
+    __shared__ P2 pts_s[16 * 256];
     for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
         const int i = (int)(t / m), j = (int)(t - (long long)i * m);
         float a[7], b[7];
@@ -704,7 +725,7 @@ __global__ __launch_bounds__(256) void boxes_iou3d_kernel(const float *__restric
         for (int k = 0; k < 7; ++k) { a[k] = A[(size_t)i * lda + k]; b[k] = B[(size_t)j * ldb + k]; }
         // iou3d_nms_utils.py:58-79 — torch ops there, same order here
         const float a_max = a[2] + a[5] / 2, a_min = a[2] - a[5] / 2, b_max = b[2] + b[5] / 2, b_min = b[2] - b[5] / 2;
-        const float ov_bev = rotated_overlap(a, b);
+        const float ov_bev = rotated_overlap<256>(a, b, pts_s + threadIdx.x);
         const float ov_h = fmaxf(fminf(a_max, b_max) - fmaxf(a_min, b_min), 0.f);
         const float ov3d = ov_bev * ov_h;
         const float va = a[3] * a[4] * a[5], vb = b[3] * b[4] * b[5];

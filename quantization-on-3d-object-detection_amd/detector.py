@@ -196,8 +196,8 @@ class Detector3DTemplate(nn.Module):
     def _async_engine(self):
         """Round-robin over the device plans of forward_async. A split plan (CenterPoint) gets two of them by default, each
         with its own buffers and index-phase stream: the index phase of frame N+1 (voxelizer + rulebook, latency-bound, on the
-        critical path at the head of a frame) runs beside the dense phase of frame N; the main phases are chained by events, so
-        the heavy kernels of different frames never contend (running whole frames concurrently measured slower)."""
+        critical path at the head of a frame) runs beside the dense phase of frame N, and the main phases of the two frames
+        in flight overlap as well (see forward_async). One frame per plan is in flight at any time."""
         primary = self.engine()
         n = max(1, int(self.async_streams)) if not primary.split_index else max(2, int(self.async_streams))
         if os.environ.get("AQ3D_SPLIT_INDEX", "1") == "0":
@@ -271,6 +271,9 @@ class CenterPoint(Detector3DTemplate):
         if B > self.max_batch_size:
             self.max_batch_size = B
         eng = self._async_engine()
+        # one frame in flight per plan: its previous frame has to be complete before its buffers are handed to the next one
+        # (pipelines deeper than the number of plans block here instead of racing; a completed event costs nothing)
+        eng._ev_done[eng.slot].synchronize()
         caller = torch.cuda.current_stream(eng.device)
         eng.ev_in.record(caller)                                   # the inputs were produced on the caller's stream
         if eng.split_index:
@@ -283,7 +286,11 @@ class CenterPoint(Detector3DTemplate):
             # main phases run one after the other, each on its own plan's main stream, chained by events
             ms = eng.main_stream
             ms.wait_event(eng.ev_idx)
-            if self._ev_prev_main is not None:
+            # The main phases of consecutive frames run on different plans and are NOT ordered against each other: a frame's
+            # kernels are latency chains with tile-quantisation tails (274 tiles on 256 CUs ...), and the other frame's kernels
+            # fill what they leave idle — 384 → 502 frames/s at two frames in flight. AQ3D_MAIN_OVERLAP=0 chains them
+            # (lowest single-frame latency).
+            if self._ev_prev_main is not None and os.environ.get("AQ3D_MAIN_OVERLAP", "1") == "0":
                 ms.wait_event(self._ev_prev_main)
             with torch.cuda.stream(ms):
                 eng.run_main(Bf)
