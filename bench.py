@@ -131,7 +131,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="centerpoint", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=2, help="frames enqueued before the oldest one is read back")
+    ap.add_argument("--inflight", type=int, default=0, help="frames enqueued before the oldest one is read back "
+                    "(default: one per device plan of the detector — 4 for CenterPoint, 2 for VoxelNeXt)")
     ap.add_argument("--breakdown", action="store_true", help="time every kernel family in an extra pass (stderr)")
     args = ap.parse_args()
 
@@ -169,6 +170,8 @@ def main():
     n_warm = max(args.warmup, 1)
     dominant = max(warm.items(), key=lambda kv: kv[1][1])[0] if warm else None
 
+    if args.inflight <= 0:
+        args.inflight = 4 if getattr(eng, "split_index", False) else 2
     # graph warm-up (untimed): the first frames without per-kernel events capture the per-slot hipGraphs the timed region replays
     with torch.no_grad():
         for i in range(4 * eng.NSLOT * max(1, args.inflight)):

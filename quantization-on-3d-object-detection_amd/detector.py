@@ -194,12 +194,13 @@ class Detector3DTemplate(nn.Module):
         return self._engine
 
     def _async_engine(self):
-        """Round-robin over the device plans of forward_async. A split plan (CenterPoint) gets two of them by default, each
+        """Round-robin over the device plans of forward_async. A split plan (CenterPoint) gets four of them by default (measured:
+        2 plans 503, 4 plans 555, 6 plans 516, 8 plans 486 frames/s with one hardware queue per stream), each
         with its own buffers and index-phase stream: the index phase of frame N+1 (voxelizer + rulebook, latency-bound, on the
-        critical path at the head of a frame) runs beside the dense phase of frame N, and the main phases of the two frames
-        in flight overlap as well (see forward_async). One frame per plan is in flight at any time."""
+        critical path at the head of a frame) runs beside the dense phase of frame N, and the main phases of the frames in flight
+        overlap as well (see forward_async). One frame per plan is in flight at any time."""
         primary = self.engine()
-        n = max(1, int(self.async_streams)) if not primary.split_index else max(2, int(self.async_streams))
+        n = max(1, int(self.async_streams)) if not primary.split_index else max(4, int(self.async_streams))
         if os.environ.get("AQ3D_SPLIT_INDEX", "1") == "0":
             n = max(1, int(self.async_streams))
         if os.environ.get("AQ3D_ASYNC_ENGINES"):
@@ -288,7 +289,7 @@ class CenterPoint(Detector3DTemplate):
             ms.wait_event(eng.ev_idx)
             # The main phases of consecutive frames run on different plans and are NOT ordered against each other: a frame's
             # kernels are latency chains with tile-quantisation tails (274 tiles on 256 CUs ...), and the other frame's kernels
-            # fill what they leave idle — 384 → 502 frames/s at two frames in flight. AQ3D_MAIN_OVERLAP=0 chains them
+            # fill what they leave idle — 384 → 503 frames/s at two frames in flight, 555 at four. AQ3D_MAIN_OVERLAP=0 chains them
             # (lowest single-frame latency).
             if self._ev_prev_main is not None and os.environ.get("AQ3D_MAIN_OVERLAP", "1") == "0":
                 ms.wait_event(self._ev_prev_main)

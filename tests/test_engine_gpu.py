@@ -92,16 +92,17 @@ def test_graph_replay_survives_later_allocations_and_a_second_plan(dev):
     with torch.no_grad():
         got = [_np(model(_batch(ds, i, dev))[0][0]) for i in range(2)]
     assert all(_same(r, g) for r, g in zip(ref, got))
-    # pipelined: frame N+1 is enqueued (its index phase runs on the second plan's stream) before frame N is read back
+    # pipelined: four frames in flight on four device plans (index phase a frame ahead, main phases overlapping)
+    import collections
     with torch.no_grad():
-        pend, outs = None, []
-        for i in range(9):
-            cur = model.forward_async(_batch(ds, i % 2, dev))
-            if pend is not None:
-                outs.append(_np(pend.result()[0][0]))
-            pend = cur
-        outs.append(_np(pend.result()[0][0]))
-    assert len(model._extra_engines) == 1 and all("idx" in e._graphs for e in [model._engine] + model._extra_engines)
+        pend, outs = collections.deque(), []
+        for i in range(33):
+            pend.append(model.forward_async(_batch(ds, i % 2, dev)))
+            if len(pend) >= 4:
+                outs.append(_np(pend.popleft().result()[0][0]))
+        while pend:
+            outs.append(_np(pend.popleft().result()[0][0]))
+    assert len(model._extra_engines) == 3 and all("idx" in e._graphs for e in [model._engine] + model._extra_engines)
     for i, o in enumerate(outs):
         assert _same(ref[i % 2], o), "pipelined frame %d differs" % i
     del junk
