@@ -36,6 +36,7 @@ struct ConvArgs {
     int pieces_ld;
     long long *stamps;      // diagnostic builds only (AQ3D_I8_STAMP)
     int pieces_mode;        // 0: 16 exact classes; 1: the four interior classes merged (all consumers have stride 1)
+    int xcd_order;          // int8 generic kernel: pixel tiles dealt to XCDs in contiguous ranges (grid x padded to 8)
 };
 
 // Up to 8 independent convolutions of one launch class in a single grid (blockIdx.z = problem): the head's per-branch convs
@@ -104,7 +105,12 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     const int g = lane >> 4, l15 = lane & 15;
     const int L = a.Ho * a.Wo;
     const int K = a.Cin * a.ks * a.ks;
-    const int pix0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups go round-robin over the 8 XCDs (each with its own L2), so consecutive block ids would
+    // scatter a 3x3 conv's vertically adjacent pixel tiles — which re-read each other's input rows — over all eight L2s.
+    // gridDim.x is a multiple of 8 (host): XCD x takes the contiguous pixel range [x, x+1) * gridDim.x/8 tiles.
+    const int bx = a.xcd_order ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int pix0 = bx * BN;
+    if (pix0 >= L) return;
     const int oc0 = blockIdx.y * BM;
     const int cchunks = a.Cin >> 6;
     if (a.pieces_out)
@@ -854,6 +860,7 @@ static int fill_args(ConvArgs *a, const float *x, const aq3d_conv2d_geom *g, con
     a->pieces_ld = 0;
     a->stamps = nullptr;
     a->pieces_mode = 0;
+    a->xcd_order = 0;
     a->w = nullptr;
     a->rows_total = g->Cout;
     return AQ3D_OK;
@@ -960,8 +967,10 @@ extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n,
     if (force_bn) bn = force_bn;
     static const int nwn_env = getenv("AQ3D_I8_WAVES") ? atoi(getenv("AQ3D_I8_WAVES")) / 2 : 0;
     const int nwn = nwn_env == 2 || nwn_env == 4 ? nwn_env : 2;      // 8 waves (AQ3D_I8_WAVES=8) measured equal to 4: the VALU op count is what binds
+    static const bool xcd = !(getenv("AQ3D_I8_XCD") && atoi(getenv("AQ3D_I8_XCD")) == 0);
+    for (int i = 0; i < AQ3D_MAX_GROUP; ++i) grp.p[i].xcd_order = xcd ? 1 : 0;
 #define AQ3D_I8_LAUNCH(TI_, TJ_, NWN_) \
-    hipLaunchKernelGGL((conv2d_i8_kernel<TI_, TJ_, NWN_>), dim3(aq3d_div_up(L, 16 * TJ_ * NWN_), ocb, n), dim3(128 * NWN_), 0, stream, grp)
+    hipLaunchKernelGGL((conv2d_i8_kernel<TI_, TJ_, NWN_>), dim3(xcd ? aq3d_div_up(aq3d_div_up(L, 16 * TJ_ * NWN_), 8) * 8 : aq3d_div_up(L, 16 * TJ_ * NWN_), ocb, n), dim3(128 * NWN_), 0, stream, grp)
     if (g->Cout >= 128) {
         if (bn == 128) { if (nwn == 4) AQ3D_I8_LAUNCH(4, 2, 4); else AQ3D_I8_LAUNCH(4, 4, 2); }
         else if (bn == 64) { if (nwn == 4) AQ3D_I8_LAUNCH(4, 1, 4); else AQ3D_I8_LAUNCH(4, 2, 2); }
