@@ -1006,11 +1006,10 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
 // fp32-pipe kernel above remains available through AQ3D_F32_EXACT=1.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-template <int WM, int WN, int TI, int TJ>
+template <int WM, int WN, int TI, int TJ, int KS>
 __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
     const ConvArgs a = grp.p[blockIdx.z];
     if ((int)blockIdx.y * WM * TI * 16 >= a.rows_total) return;
-    constexpr int KS = 32;
     constexpr int BM = WM * TI * 16;
     constexpr int BN = WN * TJ * 16;
     constexpr int LD = 2 * KS + 8;  // halves per LDS row: KS hi | KS lo | 16 B pad
@@ -1106,27 +1105,30 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
         for (int i = tid; i < 16 * BM; i += 256) pm[i] = 0u;      // ordered before its use by the K loop's barriers
 
     auto mma_step = [&](int buf) {
-        f16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
 #pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const _Float16 *r = Wbuf(buf) + (wm * TI * 16 + i * 16 + l15) * LD + g * 8;
-            ah[i] = *reinterpret_cast<const f16x8 *>(r);
-            al[i] = *reinterpret_cast<const f16x8 *>(r + KS);
-        }
+        for (int kk = 0; kk < KS / 32; ++kk) {
+            f16x8 ah[TI], al[TI], bh[TJ], bl[TJ];
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const _Float16 *r = Xbuf(buf) + (wn * TJ * 16 + j * 16 + l15) * LD + g * 8;
-            bh[j] = *reinterpret_cast<const f16x8 *>(r);
-            bl[j] = *reinterpret_cast<const f16x8 *>(r + KS);
-        }
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
+            for (int i = 0; i < TI; ++i) {
+                const _Float16 *r = Wbuf(buf) + (wm * TI * 16 + i * 16 + l15) * LD + kk * 32 + g * 8;
+                ah[i] = *reinterpret_cast<const f16x8 *>(r);
+                al[i] = *reinterpret_cast<const f16x8 *>(r + KS);
+            }
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                accl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accl[i][j], 0, 0, 0);
-                accl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accl[i][j], 0, 0, 0);
+                const _Float16 *r = Xbuf(buf) + (wn * TJ * 16 + j * 16 + l15) * LD + kk * 32 + g * 8;
+                bh[j] = *reinterpret_cast<const f16x8 *>(r);
+                bl[j] = *reinterpret_cast<const f16x8 *>(r + KS);
             }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    accl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], accl[i][j], 0, 0, 0);
+                    accl[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], accl[i][j], 0, 0, 0);
+                }
+        }
     };
     load_step(0);
     store_step(0);
@@ -1234,13 +1236,15 @@ extern "C" int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *probs, int32_t n
     bool split_ok = !exact;
     for (int i = 0; i < n; ++i) split_ok = split_ok && (probs[i].geom->Cin & 31) == 0;
     if (split_ok) {     // fp16 matrix pipe, split operands (see conv2d_f16s_kernel)
-        if (cls == 0) hipLaunchKernelGGL((conv2d_f16s_kernel<1, 4, 1, 2>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
-        else if (cls == 1) hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
-        else {
-            static const int c2 = getenv("AQ3D_F16S_CLS2") ? atoi(getenv("AQ3D_F16S_CLS2")) : 0;
-            if (c2 == 0) hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
-            else if (c2 == 1) hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 4, 2>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 128), n), dim3(256), 0, stream, grp);
-            else hipLaunchKernelGGL((conv2d_f32_kernel<2, 2, 4, 2, 16>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 128), n), dim3(256), 0, stream, grp);
+        static const int ks64 = getenv("AQ3D_F16S_KS64") ? atoi(getenv("AQ3D_F16S_KS64")) : 0;
+        bool k64 = ks64 != 0;
+        for (int i = 0; i < n; ++i) k64 = k64 && (probs[i].geom->Cin & 63) == 0;
+        if (cls == 0) {
+            if (k64) hipLaunchKernelGGL((conv2d_f16s_kernel<1, 4, 1, 2, 64>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
+            else hipLaunchKernelGGL((conv2d_f16s_kernel<1, 4, 1, 2, 32>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
+        } else {        // 64 x 64 tiles for both deblock shapes (128-row tiles measured slower: conversion work, 63 KB of LDS)
+            if (k64) hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 64>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
+            else hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 32>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
         }
         AQ3D_CHECK_LAUNCH("aq3d_conv2d_f32");
         return AQ3D_OK;

@@ -9,9 +9,9 @@ python3 - "$name" <<'PY'
 import csv, glob, sys
 f = glob.glob("gpurun_out/_stats/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
-nfr = 47.0
+nfr = max(1.0, sum(float(r["Calls"]) for r in rows if r["Name"].startswith("vox_insert")))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
-out = ["total kernel us/frame %.1f (47 frames assumed)" % (tot / nfr / 1e3)]
+out = ["total kernel us/frame %.1f (%d frames)" % (tot / nfr / 1e3, nfr)]
 for r in rows[:45]:
     out.append("%-64s n/fr %5.1f  us/fr %7.1f  avg %7.1f" % (r['Name'][:64], float(r['Calls']) / nfr, float(r['TotalDurationNs']) / nfr / 1e3, float(r['AverageNs']) / 1e3))
 open("gpurun_out/%s.txt" % sys.argv[1], "w").write("\n".join(out))
