@@ -197,6 +197,24 @@ def test_nms_rotated_keep_list(dev, n, thresh, post):
     assert np.isfinite(iou_dev_vs_ref).all()
 
 
+def test_nms_exact_duplicates_are_suppressed(dev):
+    """One pixel ranked in two classes yields the same BEV rectangle twice (the regression maps are shared). The polygon
+    clipping of a rectangle with itself is degenerate (its area was decided by last-bit ties); the overlap is the area."""
+    from amdq3d import ops
+    n = 300
+    b = _boxes(n, seed=7)
+    b[5] = [-60.930511474609375, -43.97422790527344, 1.1041380167007446, 0.350118488073349, 1.073858618736267,
+            2.750863552093506, 1.225360631942749]          # the pair that flipped on the device
+    ref = OD.nms_sorted(b, 0.7)
+    dup = np.concatenate([b, b[:40]], 0)                     # copies come later in rank order: none may survive
+    t = torch.from_numpy(dup).to(dev)
+    cnt = torch.tensor([len(dup)], dtype=torch.int32, device=dev)
+    for _ in range(3):
+        keep, kc = ops.nms_rotated(t, cnt, 0.7, 500)
+        m = int(kc.item())
+        np.testing.assert_array_equal(keep[:m].cpu().numpy(), ref)
+
+
 def test_nms_empty_and_gather(dev):
     from amdq3d import ops
     t = torch.zeros((16, 7), device=dev)
