@@ -2,7 +2,7 @@
 # with --pmc), summarised per kernel. Outputs under gpurun_out/prof_final/; copy what is to be judged into profiles/.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/prof_final3
+O=gpurun_out/prof_final4
 mkdir -p $O
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err
 export AQ3D_GRAPH=0
