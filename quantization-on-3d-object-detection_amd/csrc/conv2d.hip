@@ -115,7 +115,8 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     const int cchunks = a.Cin >> 6;
     if (a.pieces_out)
         for (int i = tid; i < 16 * BM; i += NTH) pm[i] = 0u;      // ordered before its use by the K loop's barriers
-    const int nk = a.ks * a.ks * cchunks;
+    const int ntaps = a.ks * a.ks;
+    const int nk = ntaps * cchunks;
     const float sx = a.scal[0];
     const bool clamp = a.scal[3] != 0.f;     // calibrated (static) activation amax: codes can exceed +-127 before the clamp
 
@@ -157,7 +158,10 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     }
 
     auto load_step = [&](int kstep) {
-        const int tap = kstep / cchunks, c0 = (kstep - tap * cchunks) << 6;
+        // K order: channel chunk outermost, the taps of one chunk back to back — the nine taps re-read the same fp32 pixels
+        // (shifted by a pixel or a row), so their re-use distance is one step (16 KB per workgroup) instead of Cin/64 steps:
+        // with tap-major order the 512-channel head conv fetched its input 8.6x from beyond L2. int32 sums: order-free.
+        const int chunk = kstep / ntaps, tap = kstep - chunk * ntaps, c0 = chunk << 6;
         const int kh = tap / a.ks, kw = tap - kh * a.ks;
         const int toff = (kh * a.W + kw) * a.in_ld + c0;      // wave-uniform
         const unsigned col = (unsigned)(tap * a.Cin + c0 + cq * 4) * 4u;
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
-            wreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(wrow_off[i] + kstep * 64), 0, 0));
+            wreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(wrow_off[i] + tap * a.Cin + c0), 0, 0));
     };
     auto store_step = [&](int buf) {
         if (clamp) {
