@@ -268,3 +268,20 @@ def test_quant_state_save_load_roundtrip(tmp_path):
     _, _, m3 = _model()                                   # no surgery → no quantizers → strict load must complain
     with pytest.raises(KeyError):
         Q.load_quant_state(m3, p)
+
+
+def test_import_sets_the_hip_graph_flags_before_cuda_initialises():
+    """The package has to be imported before CUDA initialises: it turns off ROCm's graph packet-capture path (captured kernel
+    arguments were corrupted by later allocations) and asks for one hardware queue per stream of the four device plans. A
+    process that initialised CUDA first gets GRAPH_REPLAY_SAFE = False and eager launches."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); "
+            "os.environ.pop('DEBUG_CLR_GRAPH_PACKET_CAPTURE', None); os.environ.pop('GPU_MAX_HW_QUEUES', None); "
+            "import amdq3d; print(amdq3d.GRAPH_REPLAY_SAFE, os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'), "
+            "os.environ.get('GPU_MAX_HW_QUEUES'))") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split()
+    assert out == ["True", "0", "8"]
+    code2 = ("import os, sys; sys.path.insert(0, %r); os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = '1'; "
+             "import amdq3d; print(amdq3d.GRAPH_REPLAY_SAFE)") % ROOT
+    assert subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, check=True).stdout.split() == ["False"]
