@@ -9,6 +9,7 @@
 Voxelization moved onto the device (aq3d_voxelize), so `prepare_data` stops after the point-level steps and the
 batch carries `points [N, 1+C]` (batch index in column 0) instead of `voxels / voxel_coords / voxel_num_points`.
 """
+import os
 from collections import defaultdict
 
 import numpy as np
@@ -162,3 +163,96 @@ class SyntheticDataset(DatasetTemplate):
         m = mask_points_by_range(d["points"], self.point_cloud_range)
         d["points"] = d["points"][m]
         return d
+
+
+# ------------------------------------------------------------------ frame readers
+def read_waymo_frame(path, disable_nlz_flag=False, tanh_dims=None):
+    """One pre-extracted Waymo frame → float32 [N, 5] (x, y, z, intensity, elongation).
+
+    Semantics of `WaymoDataset.get_lidar` (pcdet/datasets/waymo/waymo_dataset.py:196-208): the `.npy` rows are
+    (x, y, z, intensity, elongation, NLZ flag); rows inside a no-label zone (flag != -1) are dropped unless
+    DISABLE_NLZ_FLAG_ON_POINTS is set; intensity is squashed with tanh (or the dimensions listed in POINTS_TANH_DIM)."""
+    raw = np.load(str(path))
+    if raw.ndim != 2 or raw.shape[1] < 6:
+        raise ValueError("%s: expected an [N, >=6] array (x, y, z, intensity, elongation, NLZ), got %s" % (path, raw.shape))
+    pts = raw[:, 0:5].astype(np.float32, copy=True)
+    if not disable_nlz_flag:
+        pts = pts[raw[:, 5] == -1]
+    for d in ([3] if tanh_dims is None else list(tanh_dims)):
+        pts[:, d] = np.tanh(pts[:, d])
+    return pts
+
+
+def read_nuscenes_sweep(path, transform=None, time_lag=0.0, ego_radius=1.0, drop_ego=True):
+    """One nuScenes `.bin` sweep (float32 rows of 5: x, y, z, intensity, ring) → ([N, 4] points, [N, 1] time lags).
+
+    Semantics of `NuScenesDataset.get_sweep` (pcdet/datasets/nuscenes/nuscenes_dataset.py:86-100): points within
+    `ego_radius` of the sensor in both x and y are the ego vehicle and are removed; `transform` (4x4, sweep → key-frame
+    lidar) is applied to xyz in float64 and stored back as float32."""
+    raw = np.fromfile(str(path), dtype=np.float32)
+    if raw.size % 5 != 0:
+        raise ValueError("%s: %d floats is not a whole number of 5-float points" % (path, raw.size))
+    pts = raw.reshape(-1, 5)[:, :4].copy()
+    if drop_ego:
+        pts = pts[~((np.abs(pts[:, 0]) < ego_radius) & (np.abs(pts[:, 1]) < ego_radius))]
+    if transform is not None:
+        T = np.asarray(transform, dtype=np.float64)
+        xyz1 = np.concatenate([pts[:, :3].astype(np.float64), np.ones((pts.shape[0], 1))], axis=1)
+        pts[:, :3] = (xyz1 @ T.T)[:, :3].astype(np.float32)
+    return pts, np.full((pts.shape[0], 1), float(time_lag))
+
+
+def read_nuscenes_frame(root, info, max_sweeps=1, rng=None):
+    """Key frame + (max_sweeps - 1) randomly chosen previous sweeps → float32 [N, 5] (x, y, z, intensity, time lag).
+
+    Semantics of `NuScenesDataset.get_lidar_with_sweeps` (nuscenes_dataset.py:102-119): the key frame keeps its ego
+    points and has time 0; the sweeps are drawn without replacement (np.random.choice there; pass `rng` for a
+    reproducible draw), each through read_nuscenes_sweep with its `transform_matrix` and `time_lag`."""
+    key, _ = read_nuscenes_sweep(os.path.join(str(root), info["lidar_path"]), drop_ego=False)
+    parts, times = [key], [np.zeros((key.shape[0], 1))]
+    sweeps = info.get("sweeps", [])
+    n_extra = max_sweeps - 1
+    if n_extra > 0:
+        if n_extra > len(sweeps):
+            raise ValueError("frame has %d sweeps, max_sweeps=%d needs %d" % (len(sweeps), max_sweeps, n_extra))
+        pick = (rng or np.random).choice(len(sweeps), n_extra, replace=False)
+        for k in pick:
+            s = sweeps[int(k)]
+            p, t = read_nuscenes_sweep(os.path.join(str(root), s["lidar_path"]), s.get("transform_matrix"), s.get("time_lag", 0.0))
+            parts.append(p)
+            times.append(t)
+    pts = np.concatenate(parts, axis=0)
+    return np.concatenate([pts, np.concatenate(times, axis=0).astype(pts.dtype)], axis=1)
+
+
+class FrameFileDataset(DatasetTemplate):
+    """Frames from files through the same prepare_data as the reference datasets: `infos` is the list of records of the
+    reference's info pickles (Waymo: {'point_cloud': {'lidar_sequence', 'sample_idx'}, 'frame_id'}; nuScenes: {'lidar_path',
+    'sweeps': [{'lidar_path', 'transform_matrix', 'time_lag'}], 'token'}); ground-truth boxes, when a record carries
+    `gt_boxes` already in the unified lidar frame, ride along for the recall bookkeeping."""
+
+    def __init__(self, dataset_cfg, class_names, root, infos, kind, training=False, logger=None, seed=None):
+        super().__init__(dataset_cfg, class_names, training, logger)
+        if kind not in ("waymo", "nuscenes"):
+            raise ValueError("kind must be 'waymo' or 'nuscenes'")
+        self.root, self.infos, self.kind = str(root), list(infos), kind
+        self._rng = np.random.default_rng(seed) if seed is not None else None
+
+    def __len__(self):
+        return len(self.infos)
+
+    def __getitem__(self, index):
+        info = self.infos[index]
+        if self.kind == "waymo":
+            pc = info["point_cloud"]
+            path = os.path.join(self.root, pc["lidar_sequence"], "%04d.npy" % pc["sample_idx"])
+            pts = read_waymo_frame(path, bool(self.dataset_cfg.get("DISABLE_NLZ_FLAG_ON_POINTS", False)),
+                                   self.dataset_cfg.get("POINTS_TANH_DIM", None))
+            frame_id = info.get("frame_id", "%s_%03d" % (pc["lidar_sequence"], pc["sample_idx"]))
+        else:
+            pts = read_nuscenes_frame(self.root, info, int(self.dataset_cfg.get("MAX_SWEEPS", 1)), self._rng)
+            frame_id = info.get("token", os.path.basename(info["lidar_path"]))
+        d = {"points": pts, "frame_id": frame_id}
+        if "gt_boxes" in info:
+            d["gt_boxes"] = np.asarray(info["gt_boxes"], dtype=np.float32)
+        return self.prepare_data(d)

@@ -285,3 +285,66 @@ def test_import_sets_the_hip_graph_flags_before_cuda_initialises():
     code2 = ("import os, sys; sys.path.insert(0, %r); os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = '1'; "
              "import amdq3d; print(amdq3d.GRAPH_REPLAY_SAFE)") % ROOT
     assert subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, check=True).stdout.split() == ["False"]
+
+
+def test_frame_readers_waymo_npy_and_nuscenes_sweeps(tmp_path):
+    """waymo_dataset.py:196-208 (NLZ filter + tanh intensity) and nuscenes_dataset.py:86-119 (ego-point
+    removal, sweep → key-frame transform, time-lag column, random sweep choice), checked on files written here."""
+    from amdq3d.config import AttrDict, cfg_from_yaml_file
+    from amdq3d.datasets import FrameFileDataset, read_nuscenes_frame, read_nuscenes_sweep, read_waymo_frame
+    rng = np.random.default_rng(0)
+    # --- Waymo
+    seq = tmp_path / "waymo" / "segment-1"
+    seq.mkdir(parents=True)
+    raw = np.concatenate([rng.uniform(-70, 70, (500, 2)), rng.uniform(-1.5, 3.5, (500, 1)), rng.uniform(0, 40, (500, 1)),
+                          rng.uniform(0, 1, (500, 1)), rng.choice([-1.0, 1.0], (500, 1), p=[0.8, 0.2])], 1).astype(np.float32)
+    np.save(seq / "0007.npy", raw)
+    pts = read_waymo_frame(seq / "0007.npy")
+    keep = raw[:, 5] == -1
+    assert pts.shape == (int(keep.sum()), 5) and pts.dtype == np.float32
+    np.testing.assert_array_equal(pts[:, [0, 1, 2, 4]], raw[keep][:, [0, 1, 2, 4]])
+    np.testing.assert_array_equal(pts[:, 3], np.tanh(raw[keep][:, 3]))
+    assert read_waymo_frame(seq / "0007.npy", disable_nlz_flag=True).shape[0] == 500
+    np.testing.assert_array_equal(read_waymo_frame(seq / "0007.npy", tanh_dims=[4])[:, 3], raw[keep][:, 3])
+    cfg = cfg_from_yaml_file("cfgs/waymo_models/centerpoint.yaml", AttrDict())
+    ds = FrameFileDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, tmp_path / "waymo",
+                          [{"point_cloud": {"lidar_sequence": "segment-1", "sample_idx": 7}, "frame_id": "segment-1_007",
+                            "gt_boxes": np.zeros((2, 8), np.float32)}], "waymo")
+    item = ds[0]
+    r = np.asarray(cfg.DATA_CONFIG.POINT_CLOUD_RANGE, np.float32)
+    assert item["frame_id"] == "segment-1_007" and item["gt_boxes"].shape == (2, 8) and item["points"].shape[1] == 5
+    assert (item["points"][:, :3] >= r[:3]).all() and (item["points"][:, :3] <= r[3:]).all() and len(item["points"]) > 0
+    batch = ds.collate_batch([item])
+    assert batch["points"].shape[1] == 6 and batch["batch_size"] == 1
+    # --- nuScenes
+    root = tmp_path / "nusc"
+    (root / "sweeps").mkdir(parents=True)
+    def write(name, n):
+        a = np.concatenate([rng.uniform(-20, 20, (n, 3)), rng.uniform(0, 255, (n, 1)), rng.integers(0, 32, (n, 1))], 1).astype(np.float32)
+        a[:5, :2] = rng.uniform(-0.9, 0.9, (5, 2))           # ego points
+        a.tofile(root / name)
+        return a
+    key = write("key.bin", 300)
+    s0, s1 = write("sweeps/s0.bin", 200), write("sweeps/s1.bin", 100)
+    ang = 0.3
+    T = np.array([[np.cos(ang), -np.sin(ang), 0, 1.5], [np.sin(ang), np.cos(ang), 0, -0.5], [0, 0, 1, 0.2], [0, 0, 0, 1]])
+    p, t = read_nuscenes_sweep(root / "sweeps/s0.bin", T, 0.05)
+    ego = (np.abs(s0[:, 0]) < 1) & (np.abs(s0[:, 1]) < 1)
+    assert p.shape == (int((~ego).sum()), 4) and (t == 0.05).all()
+    want = (np.concatenate([s0[~ego][:, :3].astype(np.float64), np.ones((p.shape[0], 1))], 1) @ T.T)[:, :3].astype(np.float32)
+    np.testing.assert_array_equal(p[:, :3], want)
+    np.testing.assert_array_equal(p[:, 3], s0[~ego][:, 3])
+    info = {"lidar_path": "key.bin", "token": "tok", "sweeps": [{"lidar_path": "sweeps/s0.bin", "transform_matrix": T, "time_lag": 0.05},
+                                                                  {"lidar_path": "sweeps/s1.bin", "transform_matrix": None, "time_lag": 0.1}]}
+    one = read_nuscenes_frame(root, info, max_sweeps=1)
+    assert one.shape == (300, 5) and (one[:, 4] == 0).all()
+    np.testing.assert_array_equal(one[:, :4], key[:, :4])      # the key frame keeps its ego points
+    allp = read_nuscenes_frame(root, info, max_sweeps=3, rng=np.random.default_rng(1))
+    ego1 = (np.abs(s1[:, 0]) < 1) & (np.abs(s1[:, 1]) < 1)
+    assert allp.shape == (300 + int((~ego).sum()) + int((~ego1).sum()), 5) and allp.dtype == np.float32
+    assert sorted(set(allp[:, 4].tolist())) == [0.0, float(np.float32(0.05)), float(np.float32(0.1))]
+    with pytest.raises(ValueError):
+        read_nuscenes_frame(root, info, max_sweeps=4)
+    (root / "bad.bin").write_bytes(b"\0" * 12)
+    with pytest.raises(ValueError):
+        read_nuscenes_sweep(root / "bad.bin")
