@@ -495,6 +495,10 @@ class Engine:
                                 p_["pieces_out"] = (self._pieces[pkey], cin, 1)
                             self._pieces_mode[pkey] = 1
                             rec["pieces_owner"] = False
+                        elif fusable and self.fuse_pieces == "1" and all(p_["kind"] != "i8" for p_ in prods):
+                            for p_ in prods:        # fp32 producers (deblocks → bev_cat): exact classes, merged per workgroup in LDS
+                                p_["pieces_out"] = (self._pieces[pkey], cin, 0)
+                            rec["pieces_owner"] = False
                     rec["pieces"] = self._pieces[pkey]
                     rec["params"] = torch.empty((ops.sq_param_bytes(cin, g.Cout, k),), dtype=torch.uint8, device=dev)
                     rec["amax_x_acc"] = self.arena.alloc(1)
