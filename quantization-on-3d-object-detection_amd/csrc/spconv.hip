@@ -231,6 +231,156 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpconvGroup grp) {
     }
 }
 
+// fp32 activations x int8 weight codes on the fp16 matrix pipe (VoxelNeXt's weight-only QConv2d head: grouped 3x3 / 1x1 sparse
+// 2-D convs). Same tiling, gather and epilogue as spconv_kernel<.., false, true>; the staged operands are fp16 instead of fp32:
+// an activation x goes to LDS as hi = f16(x) and lo' = f16((x - hi) * 2^11) (x == hi + lo exactly; 22 significant bits), a weight
+// code is an exact small integer in fp16, and every 32-deep K chunk costs two v_mfma_f32_16x16x32_f16 (hi, then lo' scaled by
+// 2^-11 in registers — MFMA honours fp16 subnormals — into the SAME fp32 accumulator) instead of eight fp32 MFMAs of twice
+// the latency. Products are exact in fp32; only the 2^-22 tail of each activation is dropped.
+typedef _Float16 sp_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sp_f16x4 __attribute__((ext_vector_type(4)));
+template <int CIN, int COUT, int WR, int WC>
+__global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
+    const SpconvArgs a = grp.p[blockIdx.y];
+    constexpr int TM = 16 * WR;
+    constexpr int NT = COUT / (16 * WC);
+    constexpr int LDH = CIN + 8;            // halves per LDS row (16-byte pad)
+    constexpr int C4 = CIN / 4, C16 = CIN / 16;
+    static_assert(WR * WC == 4, "4 waves");
+    static_assert(COUT % (16 * WC) == 0 && CIN % 32 == 0, "shape");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    _Float16 *Ah = reinterpret_cast<_Float16 *>(lds_raw);          // [TM][LDH]
+    _Float16 *Al = Ah + TM * LDH;                                   // [TM][LDH]
+    _Float16 *Bh = Al + TM * LDH;                                   // [COUT][LDH]
+    int *nbr_s = reinterpret_cast<int *>(Bh + COUT * LDH);          // [TM][kvol]
+    float *red = reinterpret_cast<float *>(nbr_s + TM * 27);        // [WR][COUT] abs-max partials
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WR, wc = wave / WR;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int kvol = a.kvol;
+    const _Float16 s11 = (_Float16)(1.0f / 2048.f);
+    const sp_f16x8 lo_scale = {s11, s11, s11, s11, s11, s11, s11, s11};
+
+    int n = *a.count_out;
+    if (n > a.cap_out) n = a.cap_out;
+    const int ntiles = (n + TM - 1) / TM;
+    const float *fin = static_cast<const float *>(a.feats_in);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * TM;
+        __syncthreads();  // previous tile's epilogue reads of nbr_s/red are done
+        for (int t = tid; t < TM * kvol; t += 256) {
+            int r = row0 + t / kvol;
+            nbr_s[t] = (r < n) ? a.nbr[(size_t)row0 * kvol + t] : -1;
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+
+        for (int k = 0; k < kvol; ++k) {
+            int has = 0;
+            if (tid < TM) has = nbr_s[tid * kvol + k] >= 0;
+            if (!__syncthreads_or(has)) continue;  // barrier: also fences the previous offset's LDS reads
+            for (int t = tid; t < TM * C4; t += 256) {
+                const int r = t / C4, c4 = t - r * C4;
+                const int src = nbr_s[r * kvol + k];
+                f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (src >= 0) v = *reinterpret_cast<const f32x4 *>(fin + (size_t)src * CIN + c4 * 4);
+                sp_f16x4 h, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h[j] = (_Float16)v[j];
+                    l[j] = (_Float16)__fmul_rn(__fsub_rn(v[j], (float)h[j]), 2048.f);
+                }
+                *reinterpret_cast<sp_f16x4 *>(Ah + r * LDH + c4 * 4) = h;
+                *reinterpret_cast<sp_f16x4 *>(Al + r * LDH + c4 * 4) = l;
+            }
+            const int8_t *wk = static_cast<const int8_t *>(a.weight) + (size_t)k * COUT * CIN;
+            for (int t = tid; t < COUT * C16; t += 256) {
+                const int o = t / C16, c16 = t - o * C16;
+                const int4 q = *reinterpret_cast<const int4 *>(wk + (size_t)o * CIN + c16 * 16);
+                const int w[4] = {q.x, q.y, q.z, q.w};
+                sp_f16x8 lo8, hi8;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    lo8[j * 4 + 0] = (_Float16)(float)(int8_t)(w[j] & 0xff);
+                    lo8[j * 4 + 1] = (_Float16)(float)(int8_t)((w[j] >> 8) & 0xff);
+                    lo8[j * 4 + 2] = (_Float16)(float)(int8_t)((w[j] >> 16) & 0xff);
+                    lo8[j * 4 + 3] = (_Float16)(float)(int8_t)((w[j] >> 24) & 0xff);
+                    hi8[j * 4 + 0] = (_Float16)(float)(int8_t)(w[2 + j] & 0xff);
+                    hi8[j * 4 + 1] = (_Float16)(float)(int8_t)((w[2 + j] >> 8) & 0xff);
+                    hi8[j * 4 + 2] = (_Float16)(float)(int8_t)((w[2 + j] >> 16) & 0xff);
+                    hi8[j * 4 + 3] = (_Float16)(float)(int8_t)((w[2 + j] >> 24) & 0xff);
+                }
+                *reinterpret_cast<sp_f16x8 *>(Bh + o * LDH + c16 * 16) = lo8;
+                *reinterpret_cast<sp_f16x8 *>(Bh + o * LDH + c16 * 16 + 8) = hi8;
+            }
+            __syncthreads();
+
+            const _Float16 *ah = Ah + (wr * 16 + l15) * LDH + 8 * g;
+            const _Float16 *al = Al + (wr * 16 + l15) * LDH + 8 * g;
+            const _Float16 *bh = Bh + ((wc * NT) * 16 + l15) * LDH + 8 * g;
+#pragma unroll 2
+            for (int kc = 0; kc < CIN; kc += 32) {
+                const sp_f16x8 fh = *reinterpret_cast<const sp_f16x8 *>(ah + kc);
+                const sp_f16x8 fl = *reinterpret_cast<const sp_f16x8 *>(al + kc) * lo_scale;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const sp_f16x8 fb = *reinterpret_cast<const sp_f16x8 *>(bh + nt * 16 * LDH + kc);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, fb, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, fb, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- epilogue (identical to spconv_kernel). D layout: col = lane&15 (out channel), row = 4*g + reg (tile row).
+        float cmax[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int o = (wc * NT + nt) * 16 + l15;
+            const float wdq = a.w_dequant ? a.w_dequant[o] : 1.f;
+            const float b = a.bias ? a.bias[o] : 0.f;
+            const float ps = a.post_scale ? a.post_scale[o] : 1.f;
+            const float pt = a.post_shift ? a.post_shift[o] : 0.f;
+            float mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = row0 + wr * 16 + 4 * g + r;
+                if (m < n) {
+                    float v = acc[nt][r];
+                    if (a.w_dequant) v = v * wdq;
+                    if (a.bias) v = v + b;
+                    if (a.post_scale) v = v * ps + pt;
+                    if (a.residual) v += a.residual[(size_t)m * COUT + o];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.feats_out[(size_t)m * COUT + o] = v;
+                    mx = fmaxf(mx, fabsf(v));
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            cmax[nt] = mx;
+        }
+        if (a.absmax_out) {
+            if (g == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) red[wr * COUT + (wc * NT + nt) * 16 + l15] = cmax[nt];
+            }
+            __syncthreads();
+            for (int o = tid; o < COUT; o += 256) {
+                float mx = red[o];
+#pragma unroll
+                for (int w = 1; w < WR; ++w) mx = fmaxf(mx, red[w * COUT + o]);
+                if (mx > a.absmax_out[o]) aq3d_atomic_max_pos(&a.absmax_out[o], mx);
+            }
+        }
+    }
+}
+
 template <int CIN_PAD, int COUT, int WR, int WC>
 static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int w_mode, hipStream_t stream) {
     const SpconvArgs &a = grp.p[0];
@@ -245,6 +395,22 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, dim3(grid, n), dim3(256), lds, stream, grp);                                   \
     } while (0)
+    static const bool f16w = !(getenv("AQ3D_SPCONV_F16W") && atoi(getenv("AQ3D_SPCONV_F16W")) == 0);
+    if constexpr (CIN_PAD % 32 == 0) {
+        if (f16w && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_I8 && a.cin == CIN_PAD) {
+            bool same = true;
+            for (int i = 1; i < n; ++i) same = same && grp.p[i].cin == CIN_PAD;
+            if (same) {
+                constexpr size_t lds2 = (size_t)(2 * TM + COUT) * (CIN_PAD + 8) * 2 + (size_t)TM * 27 * 4 + (size_t)WR * COUT * 4;
+                auto kern = spconv_f16w_kernel<CIN_PAD, COUT, WR, WC>;
+                if (lds2 > 64 * 1024)
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+                hipLaunchKernelGGL(kern, dim3(grid, n), dim3(256), lds2, stream, grp);
+                AQ3D_CHECK_LAUNCH("aq3d_spconv");
+                return AQ3D_OK;
+            }
+        }
+    }
     if (act_mode == AQ3D_ACT_I8 && w_mode == AQ3D_W_I8) AQ3D_SPCONV_GO(true, true);
     else if (act_mode == AQ3D_ACT_I8) AQ3D_SPCONV_GO(true, false);
     else if (w_mode == AQ3D_W_I8) AQ3D_SPCONV_GO(false, true);
