@@ -39,7 +39,7 @@ class Detector3DTemplate(nn.Module):
         self._main_stream = None
         self._ev_prev_main = None
         self._rr = 0
-        self.async_streams = int(os.environ.get("AQ3D_STREAMS", "1"))   # frames that execute concurrently under forward_async
+        self.async_streams = int(os.environ.get("AQ3D_STREAMS", "1"))   # device plans of forward_async for un-split plans (VoxelNeXt: 1 plan 213, 2 plans 267 frames/s — but see DESIGN.md §9: not yet bit-reproducible with 2); split plans use max(4, this)
         self.max_batch_size = 1          # engine buffers are sized for this many frames per forward
         self.voxel_capacity = None       # rows of the sparse buffers (default MAX_NUMBER_OF_VOXELS * max_batch_size)
         self.voxelize_on_device = True   # False: consume batch_dict['voxels'/'voxel_coords'] when present

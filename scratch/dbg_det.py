@@ -4,7 +4,9 @@ import amdq3d
 import torch, bench
 from amdq3d.datasets import load_data_to_gpu
 dev = torch.device("cuda:0")
-cfg, ds, model, state = bench.build("cfgs/waymo_models/centerpoint.yaml", dev)
+wl = os.environ.get("WORKLOAD", "centerpoint")
+cfgp, npts, nvox, _ = bench.WORKLOADS[wl]
+cfg, ds, model, state = bench.build(cfgp, dev, npts, nvox)
 NF = 8
 batches = []
 for i in range(NF):
