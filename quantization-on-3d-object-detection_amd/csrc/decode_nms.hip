@@ -528,7 +528,7 @@ __device__ __forceinline__ void box_corners(const float *b, P2 *c) {
 // more or less once in a few hundred frames, inputs bit-identical); with the points in LDS the kernel has no private
 // segment and the effect is gone.
 template <int PTS_STRIDE>
-__device__ float rotated_overlap(const float *ba, const float *bb, P2 *pts_lds) {
+__device__ float rotated_overlap(const float *ba, const float *bb, P2 *pts_lds, int *cnt_out = nullptr) {
     P2 ca[5], cb[5];
     struct Pts {
         P2 *base;
@@ -563,6 +563,7 @@ __device__ float rotated_overlap(const float *ba, const float *bb, P2 *pts_lds) 
         P2 u = {pts[k].x - pts[0].x, pts[k].y - pts[0].y}, v = {pts[k + 1].x - pts[0].x, pts[k + 1].y - pts[0].y};
         area += cross2(u, v);
     }
+    if (cnt_out) *cnt_out = cnt;
     return fabsf(area) / 2.0f;
 }
 
@@ -599,6 +600,39 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
         word = __ballot(sup);
     }
     if (threadIdx.x == 0) mask[(size_t)row * col_blocks + cb] = word;
+}
+
+// Diagnostic twin of nms_mask_kernel (AQ3D_NMS_DBG=1): every pair is evaluated twice from the same registers into two LDS
+// regions; the first pair whose two overlaps differ is dumped (inputs, point counts, both point lists).
+__global__ __launch_bounds__(64) void nms_mask_dbg_kernel(const float *__restrict__ boxes, int box_ld, const int *count, int cap,
+                                                          int col_blocks, int *dbg, float *dump) {
+    int n = *count;
+    if (n > cap) n = cap;
+    const int row = blockIdx.x, cb = blockIdx.y;
+    if (row >= n) return;
+    __shared__ P2 p1[16 * 64];
+    __shared__ P2 p2[16 * 64];
+    const int j = cb * 64 + threadIdx.x;
+    if (!(cb >= (row >> 6) && j < n && j > row)) return;
+    float a[7], b[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) { a[k] = boxes[(size_t)row * box_ld + k]; b[k] = boxes[(size_t)j * box_ld + k]; }
+    int c1 = 0, c2 = 0;
+    const float o1 = rotated_overlap<64>(a, b, p1 + threadIdx.x, &c1);
+    asm volatile("" ::: "memory");
+    const float o2 = rotated_overlap<64>(a, b, p2 + threadIdx.x, &c2);
+    if (c1 > 16 || c2 > 16) atomicAdd(&dbg[2], 1);
+    if (__float_as_int(o1) != __float_as_int(o2)) {
+        if (atomicAdd(&dbg[0], 1) == 0) {
+            dbg[1] = row; dbg[3] = j; dbg[4] = c1; dbg[5] = c2;
+            for (int k = 0; k < 7; ++k) { dump[k] = a[k]; dump[8 + k] = b[k]; }
+            dump[16] = o1; dump[17] = o2;
+            for (int k = 0; k < 16; ++k) {
+                dump[20 + 2 * k] = p1[k * 64 + threadIdx.x].x; dump[21 + 2 * k] = p1[k * 64 + threadIdx.x].y;
+                dump[60 + 2 * k] = p2[k * 64 + threadIdx.x].x; dump[61 + 2 * k] = p2[k * 64 + threadIdx.x].y;
+            }
+        }
+    }
 }
 
 // greedy sweep, 64 boxes per step; the bitmask is staged in LDS by the whole workgroup when it fits, then wave 0 sweeps:
@@ -674,6 +708,28 @@ extern "C" int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_
     const int col_blocks = aq3d_div_up(cap, 64);
     u64 *mask = (u64 *)workspace;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(cap, col_blocks), dim3(64), 0, stream, boxes, box_ld, count, cap, thresh, col_blocks, mask);
+    static const bool nms_dbg = getenv("AQ3D_NMS_DBG") != nullptr;
+    if (nms_dbg) {
+        static int *dbg = nullptr;
+        static float *dump = nullptr;
+        if (!dbg) { (void)hipMalloc((void **)&dbg, 64); (void)hipMemset(dbg, 0, 64); (void)hipMalloc((void **)&dump, 512); (void)hipMemset(dump, 0, 512); }
+        if (getenv("AQ3D_NMS_DBG_DUMP")) {
+            int h[16]; float f[128];
+            (void)hipDeviceSynchronize();
+            (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost); (void)hipMemcpy(f, dump, 512, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[nmsdbg] double-eval mismatches %d, cnt>16 events %d; first: row %d j %d cnt1 %d cnt2 %d overlap1 %.9g overlap2 %.9g\n  a:", h[0], h[2], h[1], h[3], h[4], h[5], f[16], f[17]);
+            for (int k = 0; k < 7; ++k) fprintf(stderr, " %.9g", f[k]);
+            fprintf(stderr, "\n  b:");
+            for (int k = 0; k < 7; ++k) fprintf(stderr, " %.9g", f[8 + k]);
+            fprintf(stderr, "\n  pts1:");
+            for (int k = 0; k < h[4] && k < 16; ++k) fprintf(stderr, " (%.9g,%.9g)", f[20 + 2 * k], f[21 + 2 * k]);
+            fprintf(stderr, "\n  pts2:");
+            for (int k = 0; k < h[5] && k < 16; ++k) fprintf(stderr, " (%.9g,%.9g)", f[60 + 2 * k], f[61 + 2 * k]);
+            fprintf(stderr, "\n");
+        } else {
+            hipLaunchKernelGGL(nms_mask_dbg_kernel, dim3(cap, col_blocks), dim3(64), 0, stream, boxes, box_ld, count, cap, col_blocks, dbg, dump);
+        }
+    }
     const size_t mask_bytes = (size_t)cap * col_blocks * sizeof(u64);
     const int use_lds = mask_bytes <= 128 * 1024;
     if (use_lds && mask_bytes > 64 * 1024)

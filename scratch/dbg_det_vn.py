@@ -87,3 +87,8 @@ with torch.no_grad():
             check(*pend.popleft())
     while pend: check(*pend.popleft())
     print("bad", bad, "of", steps)
+    torch.cuda.synchronize()
+    if os.environ.get("AQ3D_NMS_DBG"):
+        os.environ["AQ3D_NMS_DBG_DUMP"] = "1"
+        e = model._engine; e.use_graph = False
+        model(dict(batches[0]))
