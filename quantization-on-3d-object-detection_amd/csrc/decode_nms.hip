@@ -602,10 +602,48 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
     if (threadIdx.x == 0) mask[(size_t)row * col_blocks + cb] = word;
 }
 
+// Diagnostic only (AQ3D_NMS_DBG): overlap of two rotated rectangles by Sutherland–Hodgman clipping of A against the four
+// half-planes of B and the shoelace formula — no angular sort, no containment margins; candidate for a well-conditioned NMS.
+template <int STRIDE>
+__device__ float rect_overlap_sh(const float *ba, const float *bb, P2 *buf0, P2 *buf1) {
+    P2 ca[5], cb[5];
+    box_corners(ba, ca);
+    box_corners(bb, cb);
+    int n = 4;
+    for (int k = 0; k < 4; ++k) buf0[k * STRIDE] = ca[k];
+    P2 *in = buf0, *out = buf1;
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const P2 p = cb[e], q = cb[e + 1];
+        const float dx = q.x - p.x, dy = q.y - p.y;
+        int m = 0;
+        P2 s = in[(n - 1) * STRIDE];
+        float ds = dx * (s.y - p.y) - dy * (s.x - p.x);
+        for (int i = 0; i < n; ++i) {
+            const P2 t = in[i * STRIDE];
+            const float dt = dx * (t.y - p.y) - dy * (t.x - p.x);
+            if ((ds >= 0.f) != (dt >= 0.f)) {
+                const float u = ds / (ds - dt);
+                if (m < 8) out[m * STRIDE] = P2{s.x + u * (t.x - s.x), s.y + u * (t.y - s.y)};
+                ++m;
+            }
+            if (dt >= 0.f) { if (m < 8) out[m * STRIDE] = t; ++m; }
+            s = t; ds = dt;
+        }
+        n = m < 8 ? m : 8;
+        P2 *tmp = in; in = out; out = tmp;
+    }
+    float area = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const P2 u = in[i * STRIDE], v = in[((i + 1) % n) * STRIDE];
+        area += u.x * v.y - v.x * u.y;
+    }
+    return fabsf(area) * 0.5f;
+}
+
 // Diagnostic twin of nms_mask_kernel (AQ3D_NMS_DBG=1): every pair is evaluated twice from the same registers into two LDS
 // regions; the first pair whose two overlaps differ is dumped (inputs, point counts, both point lists).
 __global__ __launch_bounds__(64) void nms_mask_dbg_kernel(const float *__restrict__ boxes, int box_ld, const int *count, int cap,
-                                                          int col_blocks, int *dbg, float *dump) {
+                                                          int col_blocks, float thresh, int *dbg, float *dump) {
     int n = *count;
     if (n > cap) n = cap;
     const int row = blockIdx.x, cb = blockIdx.y;
@@ -622,6 +660,33 @@ __global__ __launch_bounds__(64) void nms_mask_dbg_kernel(const float *__restric
     asm volatile("" ::: "memory");
     const float o2 = rotated_overlap<64>(a, b, p2 + threadIdx.x, &c2);
     if (c1 > 16 || c2 > 16) atomicAdd(&dbg[2], 1);
+    {
+        asm volatile("" ::: "memory");
+        const float h1 = rect_overlap_sh<64>(a, b, p1 + threadIdx.x, p1 + 8 * 64 + threadIdx.x);
+        asm volatile("" ::: "memory");
+        const float h2 = rect_overlap_sh<64>(a, b, p2 + threadIdx.x, p2 + 8 * 64 + threadIdx.x);
+        if (__float_as_int(h1) != __float_as_int(h2)) atomicAdd(&dbg[6], 1);
+        const float sa = a[3] * a[4], sb = b[3] * b[4];
+        const bool dref = o1 / fmaxf(sa + sb - o1, IOU_EPS) > thresh, dsh = h1 / fmaxf(sa + sb - h1, IOU_EPS) > thresh;
+        if (dref != dsh) atomicAdd(&dbg[7], 1);
+        atomicAdd(&dbg[8], 1);
+        // which stage is not reproducible: corners (sinf/cosf + affine), or only what follows?
+        P2 k1[5], k2[5];
+        box_corners(a, k1);
+        asm volatile("" ::: "memory");
+        box_corners(a, k2);
+        bool same = true;
+        for (int k = 0; k < 4; ++k) same = same && __float_as_int(k1[k].x) == __float_as_int(k2[k].x) && __float_as_int(k1[k].y) == __float_as_int(k2[k].y);
+        if (!same) atomicAdd(&dbg[9], 1);
+        const float t1 = atan2f(a[1] - b[1], a[0] - b[0]);
+        asm volatile("" ::: "memory");
+        const float t2 = atan2f(a[1] - b[1], a[0] - b[0]);
+        if (__float_as_int(t1) != __float_as_int(t2)) atomicAdd(&dbg[10], 1);
+        const float d1 = (a[0] * b[1] - a[1] * b[0]) / (a[3] - b[4] + 1.0f);
+        asm volatile("" ::: "memory");
+        const float d2 = (a[0] * b[1] - a[1] * b[0]) / (a[3] - b[4] + 1.0f);
+        if (__float_as_int(d1) != __float_as_int(d2)) atomicAdd(&dbg[11], 1);
+    }
     if (__float_as_int(o1) != __float_as_int(o2)) {
         if (atomicAdd(&dbg[0], 1) == 0) {
             dbg[1] = row; dbg[3] = j; dbg[4] = c1; dbg[5] = c2;
@@ -717,6 +782,7 @@ extern "C" int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_
             int h[16]; float f[128];
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost); (void)hipMemcpy(f, dump, 512, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[nmsdbg] pairs %d (mod 2^32); Sutherland-Hodgman: self-disagreements %d, decisions differing from the reference algorithm %d; corner mismatches %d, atan2f mismatches %d, mul-sub-div mismatches %d\n", h[8], h[6], h[7], h[9], h[10], h[11]);
             fprintf(stderr, "[nmsdbg] double-eval mismatches %d, cnt>16 events %d; first: row %d j %d cnt1 %d cnt2 %d overlap1 %.9g overlap2 %.9g\n  a:", h[0], h[2], h[1], h[3], h[4], h[5], f[16], f[17]);
             for (int k = 0; k < 7; ++k) fprintf(stderr, " %.9g", f[k]);
             fprintf(stderr, "\n  b:");
@@ -727,7 +793,7 @@ extern "C" int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_
             for (int k = 0; k < h[5] && k < 16; ++k) fprintf(stderr, " (%.9g,%.9g)", f[60 + 2 * k], f[61 + 2 * k]);
             fprintf(stderr, "\n");
         } else {
-            hipLaunchKernelGGL(nms_mask_dbg_kernel, dim3(cap, col_blocks), dim3(64), 0, stream, boxes, box_ld, count, cap, col_blocks, dbg, dump);
+            hipLaunchKernelGGL(nms_mask_dbg_kernel, dim3(cap, col_blocks), dim3(64), 0, stream, boxes, box_ld, count, cap, col_blocks, thresh, dbg, dump);
         }
     }
     const size_t mask_bytes = (size_t)cap * col_blocks * sizeof(u64);
