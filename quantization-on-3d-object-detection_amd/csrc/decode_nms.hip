@@ -640,6 +640,28 @@ __device__ float rect_overlap_sh(const float *ba, const float *bb, P2 *buf0, P2 
     return fabsf(area) * 0.5f;
 }
 
+// Diagnostic only: the edge-edge intersection stage of rotated_overlap with every index static (registers only, no LDS, no
+// scratch) — does arithmetic that never leaves the register file reproduce under co-scheduling?
+__device__ float reg_only_probe(const float *ba, const float *bb) {
+    P2 ca[5], cb[5];
+    box_corners(ba, ca);
+    box_corners(bb, cb);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            P2 ip = {0.f, 0.f};
+            if (seg_intersection(ca[i + 1], ca[i], cb[j + 1], cb[j], ip)) acc += ip.x * 0.5f + ip.y;
+        }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (corner_in_box(ba, cb[k])) acc += cb[k].x - cb[k].y;
+        if (corner_in_box(bb, ca[k])) acc += ca[k].y - ca[k].x;
+    }
+    return acc / (fabsf(ba[3] * bb[4]) + 1.0f);
+}
+
 // Diagnostic twin of nms_mask_kernel (AQ3D_NMS_DBG=1): every pair is evaluated twice from the same registers into two LDS
 // regions; the first pair whose two overlaps differ is dumped (inputs, point counts, both point lists).
 __global__ __launch_bounds__(64) void nms_mask_dbg_kernel(const float *__restrict__ boxes, int box_ld, const int *count, int cap,
@@ -686,6 +708,12 @@ __global__ __launch_bounds__(64) void nms_mask_dbg_kernel(const float *__restric
         asm volatile("" ::: "memory");
         const float d2 = (a[0] * b[1] - a[1] * b[0]) / (a[3] - b[4] + 1.0f);
         if (__float_as_int(d1) != __float_as_int(d2)) atomicAdd(&dbg[11], 1);
+        float a2[7], b2[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) { a2[k] = a[k]; b2[k] = b[k]; asm volatile("" : "+v"(a2[k]), "+v"(b2[k])); }   // opaque copies: no CSE
+        const float r1 = reg_only_probe(a, b);
+        const float r2 = reg_only_probe(a2, b2);
+        if (__float_as_int(r1) != __float_as_int(r2)) atomicAdd(&dbg[12], 1);
     }
     if (__float_as_int(o1) != __float_as_int(o2)) {
         if (atomicAdd(&dbg[0], 1) == 0) {
@@ -782,7 +810,7 @@ extern "C" int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_
             int h[16]; float f[128];
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost); (void)hipMemcpy(f, dump, 512, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[nmsdbg] pairs %d (mod 2^32); Sutherland-Hodgman: self-disagreements %d, decisions differing from the reference algorithm %d; corner mismatches %d, atan2f mismatches %d, mul-sub-div mismatches %d\n", h[8], h[6], h[7], h[9], h[10], h[11]);
+            fprintf(stderr, "[nmsdbg] pairs %d (mod 2^32); Sutherland-Hodgman: self-disagreements %d, decisions differing from the reference algorithm %d; corner mismatches %d, atan2f mismatches %d, mul-sub-div mismatches %d (these three are CSE-able, i.e. vacuous); register-only probe (opaque inputs) mismatches %d\n", h[8], h[6], h[7], h[9], h[10], h[11], h[12]);
             fprintf(stderr, "[nmsdbg] double-eval mismatches %d, cnt>16 events %d; first: row %d j %d cnt1 %d cnt2 %d overlap1 %.9g overlap2 %.9g\n  a:", h[0], h[2], h[1], h[3], h[4], h[5], f[16], f[17]);
             for (int k = 0; k < 7; ++k) fprintf(stderr, " %.9g", f[k]);
             fprintf(stderr, "\n  b:");
