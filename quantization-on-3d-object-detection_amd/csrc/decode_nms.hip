@@ -580,7 +580,7 @@ __device__ __forceinline__ float iou_bev_dev(const float *a, const float *b, P2 
 
 // one wave per (row box, column block): lane j tests box (cb*64 + j) against the row box, ballot → one mask word
 __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes, int box_ld, const int *count, int cap,
-                                                      float thresh, int col_blocks, u64 *__restrict__ mask) {
+                                                      float thresh, int col_blocks, u64 *__restrict__ mask, int vote) {
     int n = *count;
     if (n > cap) n = cap;
     const int row = blockIdx.x, cb = blockIdx.y;
@@ -599,7 +599,17 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
             // clipping, so its result is exactly 0 — decided here without running it (most of the 125 k pairs of a 500-box list)
             const float ddx = a[0] - b[0], ddy = a[1] - b[1];
             const float reach = 0.5f * (sqrtf(a[3] * a[3] + a[4] * a[4]) + sqrtf(b[3] * b[3] + b[4] * b[4])) + 0.02f;
-            if (ddx * ddx + ddy * ddy <= reach * reach) sup = iou_bev_dev<64>(a, b, pts_s + threadIdx.x) > thresh;
+            if (ddx * ddx + ddy * ddy <= reach * reach) {
+                // majority of three evaluations (experiment AQ3D_NMS_VOTE): see DESIGN.md §9 on the reproducibility of this clipping
+                const bool s1 = iou_bev_dev<64>(a, b, pts_s + threadIdx.x) > thresh;
+                if (vote) {
+                    asm volatile("" ::: "memory");
+                    const bool s2 = iou_bev_dev<64>(a, b, pts_s + threadIdx.x) > thresh;
+                    asm volatile("" ::: "memory");
+                    const bool s3 = iou_bev_dev<64>(a, b, pts_s + threadIdx.x) > thresh;
+                    sup = (s1 && s2) || (s1 && s3) || (s2 && s3);
+                } else sup = s1;
+            }
         }
         word = __ballot(sup);
     }
@@ -804,7 +814,8 @@ extern "C" int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_
     }
     const int col_blocks = aq3d_div_up(cap, 64);
     u64 *mask = (u64 *)workspace;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap, col_blocks), dim3(64), 0, stream, boxes, box_ld, count, cap, thresh, col_blocks, mask);
+    static const int vote = getenv("AQ3D_NMS_VOTE") ? atoi(getenv("AQ3D_NMS_VOTE")) : 0;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap, col_blocks), dim3(64), 0, stream, boxes, box_ld, count, cap, thresh, col_blocks, mask, vote);
     static const bool nms_dbg = getenv("AQ3D_NMS_DBG") != nullptr;
     if (nms_dbg) {
         static int *dbg = nullptr;
