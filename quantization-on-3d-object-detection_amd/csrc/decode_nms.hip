@@ -686,6 +686,7 @@ __global__ __launch_bounds__(64) void nms_mask_dbg_kernel(const float *__restric
     if (row >= n) return;
     __shared__ P2 p1[16 * 64];
     __shared__ P2 p2[16 * 64];
+    const unsigned mode0 = __builtin_amdgcn_s_getreg(0xF801);        // hwreg(HW_REG_MODE, 0, 32)
     const int j = cb * 64 + threadIdx.x;
     if (!(cb >= (row >> 6) && j < n && j > row)) return;
     float a[7], b[7];
@@ -728,6 +729,10 @@ __global__ __launch_bounds__(64) void nms_mask_dbg_kernel(const float *__restric
         const float r1 = reg_only_probe(a, b);
         const float r2 = reg_only_probe(a2, b2);
         if (__float_as_int(r1) != __float_as_int(r2)) atomicAdd(&dbg[12], 1);
+        const unsigned mode1 = __builtin_amdgcn_s_getreg(0xF801);
+        atomicMin((unsigned *)&dbg[13], mode1 & 0x3ffu);
+        atomicMax((unsigned *)&dbg[14], mode1 & 0x3ffu);
+        if (mode0 != mode1) atomicAdd(&dbg[15], 1);
     }
     if (__float_as_int(o1) != __float_as_int(o2)) {
         if (atomicAdd(&dbg[0], 1) == 0) {
@@ -820,12 +825,12 @@ extern "C" int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_
     if (nms_dbg) {
         static int *dbg = nullptr;
         static float *dump = nullptr;
-        if (!dbg) { (void)hipMalloc((void **)&dbg, 64); (void)hipMemset(dbg, 0, 64); (void)hipMalloc((void **)&dump, 512); (void)hipMemset(dump, 0, 512); }
+        if (!dbg) { (void)hipMalloc((void **)&dbg, 64); (void)hipMemset(dbg, 0, 64); { unsigned big = 0xffffffffu; (void)hipMemcpy((char *)dbg + 13 * 4, &big, 4, hipMemcpyHostToDevice); } (void)hipMalloc((void **)&dump, 512); (void)hipMemset(dump, 0, 512); }
         if (getenv("AQ3D_NMS_DBG_DUMP")) {
             int h[16]; float f[128];
             (void)hipDeviceSynchronize();
             (void)hipMemcpy(h, dbg, 64, hipMemcpyDeviceToHost); (void)hipMemcpy(f, dump, 512, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[nmsdbg] pairs %d (mod 2^32); Sutherland-Hodgman: self-disagreements %d, decisions differing from the reference algorithm %d; corner mismatches %d, atan2f mismatches %d, mul-sub-div mismatches %d (these three are CSE-able, i.e. vacuous); register-only probe (opaque inputs) mismatches %d\n", h[8], h[6], h[7], h[9], h[10], h[11], h[12]);
+            fprintf(stderr, "[nmsdbg] pairs %d (mod 2^32); Sutherland-Hodgman: self-disagreements %d, decisions differing from the reference algorithm %d; corner mismatches %d, atan2f mismatches %d, mul-sub-div mismatches %d (these three are CSE-able, i.e. vacuous); register-only probe (opaque inputs) mismatches %d; MODE[9:0] min 0x%x max 0x%x, waves whose MODE changed during the kernel %d\n", h[8], h[6], h[7], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
             fprintf(stderr, "[nmsdbg] double-eval mismatches %d, cnt>16 events %d; first: row %d j %d cnt1 %d cnt2 %d overlap1 %.9g overlap2 %.9g\n  a:", h[0], h[2], h[1], h[3], h[4], h[5], f[16], f[17]);
             for (int k = 0; k < 7; ++k) fprintf(stderr, " %.9g", f[k]);
             fprintf(stderr, "\n  b:");
