@@ -109,6 +109,8 @@ def bev_backbone(state, model_cfg, x, recipe, trace=None):
         wd = state["%sdeblocks.%d.0.weight" % (P, bi)].float()
         u = F.conv_transpose2d(x, wd, None, stride=d)                          # stays fp32 (not an nn.Conv2d)
         u = torch.relu(DN.bn2d(u, _bn(state, "%sdeblocks.%d.1" % (P, bi)), 1e-3))
+        if trace is not None:
+            trace["%sdeblocks.%d.0" % (P, bi)] = u
         ups.append(u)
     return torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
 
@@ -133,6 +135,9 @@ def center_head(state, model_cfg, class_names, x, recipe, trace=None):
             q1 = q and (not recipe.sq)
             t = torch.relu(DN.bn2d(_conv2d(state, pre + "0.0", x, 1, 1, recipe, q0), _bn(state, pre + "0.1"), eps))
             d[br] = _conv2d(state, pre + "1", t, 1, 1, recipe, q1)
+            if trace is not None:
+                trace[pre + "0.0"] = t
+                trace[pre + "1"] = d[br]
         outs.append(d)
     return outs
 
@@ -168,6 +173,8 @@ def run(state, cfg, points, recipe=Recipe(), trace=None):
     vs = [float(v) for v in vox.VOXEL_SIZE]
     feats, coords, _ = V.voxelize_mean(points, pr, vs, vox.MAX_POINTS_PER_VOXEL, vox.MAX_NUMBER_OF_VOXELS["test"])
     grid = V.grid_size_of(pr, vs)
+    if trace is not None:
+        trace["vfe"] = (feats, coords)
     sparse_shape = [int(grid[2]) + 1, int(grid[1]), int(grid[0])]
     x, idx, shape, levels = sparse_backbone(state, feats, coords, sparse_shape, recipe, trace)
     if trace is not None:

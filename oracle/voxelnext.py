@@ -196,6 +196,8 @@ def run(state, cfg, points, recipe=Recipe(), trace=None):
     vs = [float(v) for v in vox.VOXEL_SIZE]
     feats, coords, _ = V.voxelize_mean(points, pr, vs, vox.MAX_POINTS_PER_VOXEL, vox.MAX_NUMBER_OF_VOXELS["test"])
     grid = V.grid_size_of(pr, vs)
+    if trace is not None:
+        trace["vfe"] = (feats, coords)
     sparse_shape = [int(grid[2]) + 1, int(grid[1]), int(grid[0])]
     x, idx, shape, levels = sparse_backbone(state, feats, coords, sparse_shape, recipe, trace)
     if trace is not None:

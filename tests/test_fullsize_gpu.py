@@ -1,0 +1,234 @@
+"""BASELINE-size parity: the kernels are compared with the oracle at the sizes the benchmark measures —
+grid 1504x1504x40, 150 000 points / 30 000 voxels, BEV 188x188 (configs[2]); one SubM layer on the 30 000-row stage-1 site
+set (configs[1]); VoxelNeXt on a 40 000-point nuScenes-shape frame (configs[4]).
+
+  (i)   voxel coordinates and every index level bit-exact;
+  (ii)  teacher-forced per-layer parity of EVERY conv (21 sparse + 12 BEV + 2 deblocks + head convs): each layer gets the
+        oracle's input, bar 2e-5 of the layer's output scale (tests/teacher.py);
+  (iii) the fp32 model end to end at the north-star tolerance (rotated IoU >= 1 - 1e-3, |dscore| <= 1e-3);
+  (iv)  head + decode + NMS of the int8 model fed the oracle's BEV features, same tolerance.
+
+The oracle needs ~12 s per W150k frame on the GPU box's host cores; the module builds each model once.
+"""
+import numpy as np
+import pytest
+import torch
+
+import teacher
+from helpers import build_model, match_boxes
+from oracle import centerpoint as OC
+from oracle import sparse as OS
+from oracle import voxelnext as OV
+
+pytestmark = pytest.mark.gpu
+
+TOL_LAYER = 2e-5        # teacher-forced int8 / fp32 layers: max |device - oracle| / max(1, max |oracle|)
+
+
+def _full_cfg(kind):
+    from amdq3d.config import AttrDict, cfg_from_yaml_file
+    path = {"waymo": "cfgs/waymo_models/centerpoint.yaml",
+            "voxelnext": "cfgs/nuscenes_models/cbgs_voxel0075_voxelnext.yaml"}[kind]
+    return cfg_from_yaml_file(path, AttrDict())
+
+
+def _state(model):
+    return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+
+def _run_gpu(model, ds, index, dev):
+    from amdq3d.datasets import load_data_to_gpu
+    batch = ds.collate_batch([ds[index]])
+    load_data_to_gpu(batch, dev)
+    with torch.no_grad():
+        pred, _ = model(batch)
+    return pred[0]
+
+
+def _preds(pred):
+    return pred["pred_boxes"].cpu().numpy(), pred["pred_scores"].cpu().numpy(), pred["pred_labels"].cpu().numpy()
+
+
+def _assert_layers(res, tol=TOL_LAYER):
+    bad = [(p, k, e) for p, k, e, _ in res if not e <= tol]
+    assert not bad, "layers above %.1e of their output scale: %s" % (tol, bad)
+
+
+# ------------------------------------------------------------------ configs[2]: full CenterPoint on W150k
+@pytest.fixture(scope="module")
+def w150k(dev):
+    cfg = _full_cfg("waymo")
+    ds, model = build_model(cfg, n_points=150000, n_voxels=30000, n_frames=1)
+    model.voxel_capacity = 65536
+    state = _state(model)
+    pts = ds[0]["points"]
+    assert pts.shape == (150000, 5)
+    return dict(cfg=cfg, ds=ds, model=model, state=state, pts=pts)
+
+
+def _cp_index_sets(trace):
+    return [trace["vfe"][1]] + [trace["levels"][n][1] for n in ("x_conv2", "x_conv3", "x_conv4")] + [trace["encoded"][1]]
+
+
+def test_w150k_fp32_end_to_end(dev, w150k):
+    """(i) + (iii): unquantized model on the full grid."""
+    cfg, ds, model, state, pts = (w150k[k] for k in ("cfg", "ds", "model", "state", "pts"))
+    model.cuda()
+    pred = _run_gpu(model, ds, 0, dev)
+    trace = {}
+    b_ref, s_ref, l_ref = OC.run(state, cfg, pts, None, trace)
+    eng = model.engine()
+    assert eng.grid_size == [1504, 1504, 40] and eng.levels[0]["shape"] == [41, 1504, 1504]
+    assert int(eng.levels[0]["count"].item()) == 30000
+    maps = teacher.row_maps(eng, _cp_index_sets(trace))                 # asserts every level's site set bit-exact
+    # voxel features (hard voxelization + mean) bit-exact, in first-seen order on both sides
+    np.testing.assert_array_equal(eng.vfe_feats[:30000].cpu().numpy(), trace["vfe"][0][maps[0]])
+    same_order = np.array_equal(eng.levels[0]["coords"][:30000].cpu().numpy(), trace["vfe"][1])
+    print("voxel rows in the oracle's first-seen order:", same_order)
+    x, idx, shape = trace["encoded"]
+    fo = eng.encoded[0]["buf"][:len(idx)].cpu().numpy()
+    assert np.abs(fo - x[maps[4]]).max() <= 1e-4 * max(1.0, float(np.abs(x).max()))
+    bev = trace["spatial_features_2d"][0].permute(1, 2, 0).numpy()
+    assert bev.shape == (188, 188, 512)
+    assert np.abs(eng.bev_cat[0].cpu().numpy() - bev).max() <= 1e-4 * max(1.0, float(np.abs(bev).max()))
+    pb, ps, pl = _preds(pred)
+    print("W150k fp32: %d boxes (oracle %d)" % (len(ps), len(s_ref)))
+    assert len(s_ref) > 50
+    assert abs(len(ps) - len(s_ref)) <= max(2, len(s_ref) // 50)
+    assert match_boxes(b_ref, s_ref, l_ref, pb, ps, pl) >= 0.98
+    assert match_boxes(pb, ps, pl, b_ref, s_ref, l_ref) >= 0.98
+    # (ii) for the fp32 plan as well: every layer on the oracle's input
+    res = teacher.sparse_layers(eng, maps, lambda n: trace["vfe"][0] if n == "vfe" else trace[n])
+    res += teacher.dense_layers(eng, lambda n: trace[n])
+    teacher.report("W150k fp32 model, teacher-forced layers", res)
+    _assert_layers(res, 1e-5)
+
+
+def test_w150k_int8_teacher_forced(dev, w150k):
+    """(i) + (ii) + (iv) for the SmoothQuant w8a8 recipe the benchmark runs."""
+    from amdq3d import quant as Qz
+    cfg, ds, model, state, pts = (w150k[k] for k in ("cfg", "ds", "model", "state", "pts"))
+    Qz.quant(model, 8, 8, sq=True, alpha=0.5, static=False)
+    model.cuda()
+    _run_gpu(model, ds, 0, dev)
+    trace = {}
+    b_ref, s_ref, l_ref = OC.run(state, cfg, pts, OC.Recipe(8, 8, True, 0.5), trace)
+    eng = model.engine()
+    maps = teacher.row_maps(eng, _cp_index_sets(trace))
+    res_s = teacher.sparse_layers(eng, maps, lambda n: trace["vfe"][0] if n == "vfe" else trace[n])
+    teacher.report("W150k SmoothQuant w8a8, teacher-forced sparse layers", res_s)
+    res_d = teacher.dense_layers(eng, lambda n: trace[n])
+    teacher.report("W150k SmoothQuant w8a8, teacher-forced dense layers", res_d)
+    assert len(res_s) == 21 and len(res_d) == len(eng.dense_convs) >= 12 + 2 + 1 + 2 * 5
+    _assert_layers(res_s)
+    _assert_layers(res_d)
+    # (iv) boxes from the oracle's BEV features
+    bev = trace["spatial_features_2d"][0].permute(1, 2, 0).numpy()
+    B = eng.run_head_from(torch.from_numpy(np.ascontiguousarray(bev))[None].to(dev))
+    pb, ps, pl = _preds(eng.collect(B)[0])
+    print("W150k int8 head on oracle features: %d boxes (oracle %d)" % (len(ps), len(s_ref)))
+    assert len(s_ref) > 50
+    assert abs(len(ps) - len(s_ref)) <= max(2, len(s_ref) // 50)
+    assert match_boxes(b_ref, s_ref, l_ref, pb, ps, pl) >= 0.98
+    assert match_boxes(pb, ps, pl, b_ref, s_ref, l_ref) >= 0.98
+
+
+# ------------------------------------------------------------------ configs[1]: one SubM layer, 30 000 active voxels
+@pytest.mark.parametrize("C", [16, 64, 128])
+def test_subm_layer_30k(dev, w150k, C):
+    """aq3d_quantize_rows + aq3d_spconv on the stage-1 site set of W150k vs oracle.sparse (qconv_act + gather_conv)."""
+    from amdq3d import ops
+    from oracle import voxel as V
+    cfg = w150k["cfg"]
+    pr = [float(v) for v in cfg.DATA_CONFIG.POINT_CLOUD_RANGE]
+    vox = {c.NAME: c for c in cfg.DATA_CONFIG.DATA_PROCESSOR}["transform_points_to_voxels"]
+    _, idx, _ = V.voxelize_mean(w150k["pts"], pr, [float(v) for v in vox.VOXEL_SIZE], 5, 150000)
+    m = len(idx)
+    assert m == 30000
+    shape = [41, 1504, 1504]
+    rng = np.random.default_rng(C)
+    x = np.maximum(rng.standard_normal((m, C)), 0).astype(np.float32)
+    w = (rng.standard_normal((C, 3, 3, 3, C)) / np.sqrt(13 * C)).astype(np.float32)
+    bias = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    wq, codes, wdiv = OS.qconv_weight(w, 8)
+    nbr_ref = OS.subm_neighbors(idx, shape)
+    xq, _ = OS.qconv_act(x, 8, cw=True)
+    ref = np.maximum(OS.gather_conv(xq, wq, nbr_ref, bias), 0)
+    coords = torch.from_numpy(idx.astype(np.int32)).to(dev)
+    count = torch.tensor([m], dtype=torch.int32, device=dev)
+    table = ops.hash_build(coords, count, shape)
+    nbr = ops.subm_neighbors(coords, count, shape, (3, 3, 3), table)
+    np.testing.assert_array_equal(nbr.cpu().numpy(), nbr_ref)          # gather table bit-exact (same row order on both sides)
+    xd = torch.from_numpy(x).to(dev)
+    amax = ops.absmax_cols(xd, count)
+    _, _, _, split = ops.quantize_rows(xd, amax, count, want_codes=False, want_split=True)
+    wk = torch.from_numpy(np.ascontiguousarray(codes.reshape(C, 27, C).transpose(1, 0, 2))).to(dev).to(torch.float16)
+    wdq = torch.from_numpy((np.float32(1) / wdiv).astype(np.float32)).to(dev)
+    am_out = torch.zeros(C, device=dev)
+    y = ops.spconv(split, wk, nbr, count, C, w_dequant=wdq, bias=torch.from_numpy(bias).to(dev), relu=True, absmax_out=am_out)
+    out = y[:m].cpu().numpy()
+    err = np.abs(out - ref).max() / max(1.0, float(np.abs(ref).max()))
+    print("SubM %d->%d @ %d voxels, %d pairs: max err %.3e of the output scale" % (C, C, m, int((nbr_ref >= 0).sum()), err))
+    assert err <= TOL_LAYER
+    np.testing.assert_allclose(am_out.cpu().numpy(), np.abs(ref).max(axis=0), rtol=0, atol=TOL_LAYER * max(1.0, float(np.abs(ref).max())))
+
+
+# ------------------------------------------------------------------ configs[4]: VoxelNeXt on S40k
+@pytest.fixture(scope="module")
+def s40k(dev):
+    cfg = _full_cfg("voxelnext")
+    ds, model = build_model(cfg, n_points=40000, n_voxels=20000, n_frames=1)
+    model.voxel_capacity = 65536
+    state = _state(model)
+    return dict(cfg=cfg, ds=ds, model=model, state=state, pts=ds[0]["points"])
+
+
+def _vn_index_sets(trace):
+    return [trace["levels"]["x_conv%d" % i][1] for i in range(1, 7)] + [trace["bev_out"][1], trace["encoded"][1]]
+
+
+def _vn_rows(trace):
+    def rows(n):
+        if n == "vfe":
+            return trace["vfe"][0]
+        if n == "backbone_3d.bev_out":
+            return trace["bev_out"][0]
+        return trace[n]
+    return rows
+
+
+def test_s40k_voxelnext_fp32_end_to_end(dev, s40k):
+    cfg, ds, model, state, pts = (s40k[k] for k in ("cfg", "ds", "model", "state", "pts"))
+    model.cuda()
+    pred = _run_gpu(model, ds, 0, dev)
+    trace = {}
+    b_ref, s_ref, l_ref = OV.run(state, cfg, pts, None, trace)
+    eng = model.engine()
+    assert eng.grid_size == [1440, 1440, 40]
+    maps = teacher.row_maps(eng, _vn_index_sets(trace))
+    pb, ps, pl = _preds(pred)
+    print("S40k VoxelNeXt fp32: %d boxes (oracle %d)" % (len(ps), len(s_ref)))
+    assert len(s_ref) > 10
+    assert abs(len(ps) - len(s_ref)) <= max(2, len(s_ref) // 50)
+    assert match_boxes(b_ref, s_ref, l_ref, pb, ps, pl) >= 0.98
+    assert match_boxes(pb, ps, pl, b_ref, s_ref, l_ref) >= 0.98
+    res = teacher.sparse_layers(eng, maps, _vn_rows(trace))
+    teacher.report("S40k VoxelNeXt fp32, teacher-forced layers", res)
+    _assert_layers(res, 1e-5)
+
+
+def test_s40k_voxelnext_int8_teacher_forced(dev, s40k):
+    from amdq3d import quant as Qz
+    cfg, ds, model, state, pts = (s40k[k] for k in ("cfg", "ds", "model", "state", "pts"))
+    Qz.dynamic_quant_voxelnext(model, 8, 8, sq=True)
+    model.cuda()
+    _run_gpu(model, ds, 0, dev)
+    trace = {}
+    OV.run(state, cfg, pts, OV.Recipe(8, 8, True), trace)
+    eng = model.engine()
+    maps = teacher.row_maps(eng, _vn_index_sets(trace))
+    # bev_out (union of three levels, fixed summation order) on the oracle's level features
+    res = teacher.sparse_layers(eng, maps, _vn_rows(trace))
+    teacher.report("S40k VoxelNeXt int8 (w8a8 3-D, weight-only 2-D), teacher-forced layers", res)
+    assert len(res) == len(eng.sparse_convs)
+    _assert_layers(res)
