@@ -196,6 +196,26 @@ typedef struct aq3d_spconv_problem {
 int aq3d_spconv_group(const aq3d_spconv_problem *problems, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
                       int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, void *stream);
 
+/* ------------- production path of the QConvNd layers: int8-coded activations, scale folded into a per-frame weight copy ----
+ * Replaces, for quant/quant.py:36-58 (QConvNd.forward) around the spconv call sites pcdet/models/backbones_3d/
+ * spconv_backbone.py:12-17,39-46, the pair aq3d_quantize_rows(split_out) + aq3d_spconv(AQ3D_ACT_F16SPLIT):
+ *   y[m,o] = sum_{k,c} (q[nbr[m][k],c] * d_c) * (wq[k,o,c] * t_o) = (sum q * W') * (S * t_o),  W' = wq * (d_c / S), S = max_c d_c.
+ * aq3d_spconv_prep (ONE launch): TensorQuantizer(axis=1) of x f32 [*count, C] with the given abs-max -> codes_out i8 [cap, C]
+ *   (1 byte per element; for C >= 64 the bytes of every 64-channel group are permuted, an internal layout only
+ *   aq3d_spconv_coded reads), AND the per-frame weight copy wprep_out (aq3d_spconv_wprep_bytes: W' as fp16 hi | lo planes,
+ *   22 significant bits) + out_mul_out f32 [Cout] = S * w_dequant. weight_codes i8 [kvol, Cout, C]; bits <= 8.
+ * aq3d_spconv_coded: the gather-GEMM with the epilogue of aq3d_spconv. perm (may be NULL): row i of nbr / of the tile order
+ *   is output row perm[i] (tiles of rows with similar neighbour patterns skip kernel offsets none of their rows has). */
+int aq3d_spconv_coded_supported(int32_t cin, int32_t cout, int32_t kvol);
+size_t aq3d_spconv_wprep_bytes(int32_t cin, int32_t cout, int32_t kvol);
+int aq3d_spconv_prep(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C, int32_t bits,
+                     int32_t per_tensor, const int8_t *weight_codes, const float *w_dequant, int32_t kvol, int32_t cout,
+                     int8_t *codes_out, void *wprep_out, float *out_mul_out, void *stream);
+int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void *wprep, const float *out_mul, const float *bias,
+                      const float *post_scale, const float *post_shift, const float *residual, const int32_t *nbr,
+                      const int32_t *perm, const int32_t *count_out, int32_t cap_out, int32_t cin, int32_t cout, int32_t kvol,
+                      int32_t flags, float *feats_out, float *absmax_out, void *stream);
+
 /* ---------------------------------------------------------------- sparse → dense -------------- */
 
 /* out f32 NHWC [B, H, W, C*D] zero-filled then out[b, y, x, c*D + z] = feats[m, c]. shape = (D, H, W). */

@@ -1,0 +1,564 @@
+// Sparse conv on int8-CODED activations (1 byte per gathered element) with the per-input-channel activation scale folded into
+// a per-frame fp16 weight copy — the production path of the QConvNd layers (quant/quant.py:36-58 around spconv).
+//
+// QConvNd quantises activations PER INPUT CHANNEL, so the scale d_c sits inside the K contraction:
+//     y[m,o] = sum_{k,c} (q[nbr(m,k),c] * d_c) * (wq[k,o,c] * t_o).
+// Here the gather moves the CODE q (int8, exact in fp16) and the scale moves into the weights:
+//     W'[k,o,c] = wq[k,o,c] * (d_c / S),  S = max_c d_c,     y = (sum q * W') * (S * t_o)
+// with W' held as an fp16 pair W' = hi + lo (hi = fp16(W'), lo = fp16(W' - hi): 22 significant bits; |W'| <= 127 so lo stays
+// above the fp16 subnormal floor wherever it matters, and the matrix pipe honours subnormals). q * hi and q * lo are exact
+// fp32 products of v_mfma_f32_16x16x32_f16 and ONE fp32 accumulator takes both. Against the round-1 format (activations as an
+// fp16 hi|lo pair, 4 bytes per element and 4 gather instructions per row and 64-channel unit) the gather moves 4x fewer bytes
+// with 4x fewer instructions at the same MFMA count; W' (27*C^2 elements) is rebuilt per frame by the quantiser launch.
+//
+//   sp_prep_kernel      one launch per layer: blocks [0, row_blocks) quantise the producer's fp32 rows to codes, the rest
+//                       build W' (hi | lo planes) and the epilogue multipliers S * t_o. Both depend on the abs-max only.
+//   spconv_cd_kernel    Cin = 16, kvol = 27: whole W' resident in LDS, per-lane 8-byte gathers straight into MFMA registers.
+//   spconv_cw_kernel    Cin >= 32: 128 rows x all Cout per workgroup, W' streamed through double-buffered LDS in
+//                       (kernel offset, 64-channel) units, A fragments gathered into registers (one 16-byte load per row and unit).
+// Code layout: rows of Cin bytes; for Cin >= 64 the bytes of every 64-channel group are permuted so that the 16 bytes a lane
+// loads are the 8 + 8 channels of its two MFMA K chunks: position 16g + 8kc + i  <->  channel 32kc + 8g + i.
+#include "common.h"
+#include <stdlib.h>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x2v __attribute__((ext_vector_type(2)));
+#define CD_OOB 0xfffffff0u
+
+// 4 packed int8 -> 4 fp16 (exact) in 5 VALU ops: bias to unsigned, splice each byte under the fp16 exponent of 1024
+// (0x64xx = 1024 + xx), subtract 1152 = 1024 + 128 with a packed add.
+__device__ __forceinline__ void cd_cvt4(int w, f16x2 &lo, f16x2 &hi) {
+    const unsigned t = (unsigned)w ^ 0x80808080u;
+    const unsigned p0 = __builtin_amdgcn_perm(t, 0x64646464u, 0x00050004u);
+    const unsigned p1 = __builtin_amdgcn_perm(t, 0x64646464u, 0x00070006u);
+    const f16x2 bias = {(_Float16)1152.f, (_Float16)1152.f};
+    lo = __builtin_bit_cast(f16x2, p0) - bias;
+    hi = __builtin_bit_cast(f16x2, p1) - bias;
+}
+__device__ __forceinline__ f16x8 cd_cvt8(int w0, int w1) {
+    f16x2 a, b, c, d;
+    cd_cvt4(w0, a, b);
+    cd_cvt4(w1, c, d);
+    f16x8 r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1]; r[4] = c[0]; r[5] = c[1]; r[6] = d[0]; r[7] = d[1];
+    return r;
+}
+
+// position of channel c inside a code row (identity below 64 channels)
+__host__ __device__ __forceinline__ int cd_code_pos(int c, int C) {
+    if (C < 64) return c;
+    const int grp = c >> 6, w = c & 63;
+    return (grp << 6) + 16 * ((w & 31) >> 3) + 8 * (w >> 5) + (w & 7);
+}
+
+// ------------------------------------------------------------------ quantiser + W' builder
+struct SpPrepArgs {
+    const float *x;           // [cap][C] producer output (fp32)
+    const float *amax;        // [C] per-channel abs-max (dynamic: this frame's; static: calibrated)
+    const int *count;
+    int cap, C;
+    float qmax;
+    int per_tensor;
+    int8_t *codes;            // [cap][C]
+    const int8_t *w;          // [kvol][Cout][C] weight codes
+    const float *w_dequant;   // [Cout]
+    _Float16 *wp;             // [kvol][Cout][2][C]   hi | lo planes
+    float *out_mul;           // [Cout]  S * t_o
+    int kvol, cout, row_blocks;
+};
+
+__global__ __launch_bounds__(256) void sp_prep_kernel(SpPrepArgs a) {
+    __shared__ float s_scale[256];     // multiply: qmax / amax (0 for dead channels)
+    __shared__ float s_dq[256];        // dequant step d_c = 1 / div
+    __shared__ float s_S;
+    const int C = a.C;
+    if (threadIdx.x < C) {
+        float am = a.amax[threadIdx.x];
+        if (a.per_tensor) {
+            am = 0.f;
+            for (int c = 0; c < C; ++c) am = fmaxf(am, a.amax[c]);
+        }
+        const float eps = 1.0f / (float)(1 << 24);
+        float scale = __fdiv_rn(a.qmax, am);
+        float dv = scale;
+        if (am <= eps) { scale = 0.f; dv = 1.f; }
+        s_scale[threadIdx.x] = scale;
+        s_dq[threadIdx.x] = scale == 0.f ? 0.f : __fdiv_rn(1.0f, dv);     // dead channel: every code is 0, its weights may be 0 too
+    }
+    __syncthreads();
+    if ((int)blockIdx.x < a.row_blocks) {
+        int n = *a.count;
+        if (n > a.cap) n = a.cap;
+        const int C4 = C >> 2, total4 = n * C4;
+        for (int t = blockIdx.x * 256 + threadIdx.x; t < total4; t += a.row_blocks * 256) {
+            const int r = t / C4, c = (t - r * C4) * 4;
+            const float4 xv = reinterpret_cast<const float4 *>(a.x)[t];
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            signed char qc[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float q = rintf(__fmul_rn(xs[k], s_scale[c + k]));
+                q = fminf(fmaxf(q, -a.qmax - 1.f), a.qmax);
+                qc[k] = (signed char)(int)q;
+            }
+            *reinterpret_cast<char4 *>(a.codes + (size_t)r * C + cd_code_pos(c, C)) = make_char4(qc[0], qc[1], qc[2], qc[3]);
+        }
+        return;
+    }
+    // weight blocks: S = largest live step; W' = code * (d_c / S) as hi | lo
+    if (threadIdx.x == 0) {
+        float S = 0.f;
+        for (int c = 0; c < C; ++c) S = fmaxf(S, s_dq[c]);
+        s_S = S > 0.f ? S : 1.f;
+    }
+    __syncthreads();
+    const float S = s_S;
+    const int wb = (int)blockIdx.x - a.row_blocks, nwb = (int)gridDim.x - a.row_blocks;
+    if (wb == 0)
+        for (int o = threadIdx.x; o < a.cout; o += 256) a.out_mul[o] = __fmul_rn(S, a.w_dequant[o]);
+    const int C8 = C >> 3, total8 = a.kvol * a.cout * C8;
+    for (int t = wb * 256 + threadIdx.x; t < total8; t += nwb * 256) {
+        const int ko = t / C8, c0 = (t - ko * C8) * 8;
+        const i32x2v wv = *reinterpret_cast<const i32x2v *>(a.w + (size_t)ko * C + c0);
+        f16x8 hi, lo;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int code = (int)(signed char)((i < 4 ? wv.x : wv.y) >> (8 * (i & 3)));
+            const float rel = __fdiv_rn(s_dq[c0 + i], S);
+            const float v = __fmul_rn((float)code, rel);
+            const _Float16 h = (_Float16)v;
+            hi[i] = h;
+            lo[i] = (_Float16)__fsub_rn(v, (float)h);
+        }
+        *reinterpret_cast<f16x8 *>(a.wp + ((size_t)ko * 2 + 0) * C + c0) = hi;
+        *reinterpret_cast<f16x8 *>(a.wp + ((size_t)ko * 2 + 1) * C + c0) = lo;
+    }
+}
+
+// ------------------------------------------------------------------ conv kernels
+struct SpCodedArgs {
+    const int8_t *codes;      // [cap_in][CIN]
+    const _Float16 *wp;       // [kvol][COUT][2][CIN]
+    const float *out_mul;     // [COUT]
+    const float *bias, *post_scale, *post_shift, *residual;
+    const int *nbr;           // [cap_out][kvol]   (rows in TILE order when perm != nullptr)
+    const int *perm;          // [cap_out] tile order -> output row, or nullptr (identity)
+    const int *count_out;
+    float *feats_out, *absmax_out;
+    int cap_out, kvol, relu;
+    unsigned codes_bytes;
+};
+
+// Cin = 16: K chunk = 2 kernel offsets x 16 channels; lane (l15, g) holds 8 channels of offset 2q + (g >> 1).
+template <int COUT, int KVOL, int NW>
+__global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
+    constexpr int CIN = 16;
+    constexpr int NTH = 64 * NW, TMW = 16 * NW;
+    constexpr int NT = COUT / 16;
+    constexpr int KT = KVOL * CIN;
+    constexpr int NCH = (KT + 31) / 32;
+    constexpr int LD = NCH * 32 + 8;                     // halves per LDS weight row (16-byte pad)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16 *Bh = reinterpret_cast<_Float16 *>(smem_raw);          // [COUT][LD] hi, K index = offset * CIN + channel
+    _Float16 *Bl = Bh + COUT * LD;                                   // [COUT][LD] lo
+    float *red = reinterpret_cast<float *>(Bl + COUT * LD);          // [NW][COUT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    int n = *a.count_out;
+    if (n > a.cap_out) n = a.cap_out;
+    const int ntiles = (n + TMW - 1) / TMW;
+    const auto rsrc_f = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, (int)a.codes_bytes, 0x00020000);
+    const auto rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, a.cap_out * KVOL * 4, 0x00020000);
+
+    for (int t = tid; t < 2 * COUT * (LD / 8); t += NTH) {
+        const int pl = t / (COUT * (LD / 8)), r = t % (COUT * (LD / 8));
+        const int o = r / (LD / 8), kk = (r % (LD / 8)) * 8;
+        i32x4v v = (i32x4v){0, 0, 0, 0};
+        if (kk < KT) v = *reinterpret_cast<const i32x4v *>(a.wp + (((size_t)(kk / CIN) * COUT + o) * 2 + pl) * CIN + (kk % CIN));
+        *reinterpret_cast<i32x4v *>((pl ? Bl : Bh) + o * LD + kk) = v;
+    }
+    __syncthreads();
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int trow = tile * TMW + wave * 16 + l15;                // position in tile order
+        int nb[KVOL];
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) {
+            const unsigned off = trow < n ? (unsigned)((trow * KVOL + k) * 4) : CD_OOB;
+            nb[k] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc_n, off, 0, 0);
+        }
+        if (trow >= n) {
+#pragma unroll
+            for (int k = 0; k < KVOL; ++k) nb[k] = -1;
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int bofs = l15 * LD + 8 * g;
+#pragma unroll
+        for (int q = 0; q < NCH; ++q) {
+            const int j0 = 2 * q, j1 = 2 * q + 1;
+            const int i0 = nb[j0 < KVOL ? j0 : KVOL - 1];
+            const int i1 = j1 < KVOL ? nb[j1 < KVOL ? j1 : KVOL - 1] : -1;
+            const int idx = (g >> 1) ? i1 : i0;
+            const unsigned off = idx >= 0 ? (unsigned)(idx * CIN + (g & 1) * 8) : CD_OOB;
+            const i32x2v cv = __builtin_amdgcn_raw_buffer_load_b64(rsrc_f, off, 0, 0);
+            const f16x8 fa = cd_cvt8(cv.x, cv.y);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const f16x8 fh = *reinterpret_cast<const f16x8 *>(Bh + bofs + nt * 16 * LD + q * 32);
+                const f16x8 fl = *reinterpret_cast<const f16x8 *>(Bl + bofs + nt * 16 * LD + q * 32);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fh, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fl, acc[nt], 0, 0, 0);
+            }
+        }
+        // epilogue (D layout: col = lane&15 -> out channel, row = 4g + reg)
+        float cmax[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int o = nt * 16 + l15;
+            const float mul = a.out_mul[o];
+            const float b = a.bias ? a.bias[o] : 0.f;
+            const float ps = a.post_scale ? a.post_scale[o] : 1.f;
+            const float pt = a.post_shift ? a.post_shift[o] : 0.f;
+            float mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tr = tile * TMW + wave * 16 + 4 * g + r;
+                if (tr < n) {
+                    const int m = a.perm ? a.perm[tr] : tr;
+                    float v = __fmul_rn(acc[nt][r], mul);
+                    if (a.bias) v = __fadd_rn(v, b);
+                    if (a.post_scale) v = __fadd_rn(__fmul_rn(v, ps), pt);
+                    if (a.residual) v = __fadd_rn(v, a.residual[(size_t)m * COUT + o]);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.feats_out[(size_t)m * COUT + o] = v;
+                    mx = fmaxf(mx, fabsf(v));
+                }
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            cmax[nt] = mx;
+        }
+        if (a.absmax_out) {
+            __syncthreads();
+            if (g == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) red[wave * COUT + nt * 16 + l15] = cmax[nt];
+            }
+            __syncthreads();
+            for (int o = tid; o < COUT; o += NTH) {
+                float mx = red[o];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w * COUT + o]);
+                if (mx > a.absmax_out[o]) aq3d_atomic_max_pos(&a.absmax_out[o], mx);
+            }
+        }
+    }
+}
+
+// Cin >= 32. Unit of work = (kernel offset k, 64-channel slice h) [32 channels when Cin = 32]: the two W' planes of the
+// slice go through LDS (double buffered, XOR-swizzled 128-byte rows as in the round-1 wide kernel), the A fragments of the
+// wave's two 16-row tiles are gathered straight into registers: ONE bounded buffer load per row and unit (16 bytes = the
+// 8 + 8 channels of the lane's two K chunks; 8 bytes when Cin = 32), missing neighbour = out-of-range offset = zeros.
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
+    constexpr int RT = 2;
+    constexpr int TM = 4 * RT * 16;
+    constexpr int NT = COUT / 16;
+    constexpr int UC = CIN < 64 ? CIN : 64;
+    constexpr int NU = CIN / UC;
+    constexpr int KC = UC / 32;
+    constexpr bool SWZ = UC == 64;
+    constexpr int LDW = SWZ ? UC : UC + 8;              // halves per LDS weight row of one plane
+    constexpr int PCH = COUT * UC / 8;                  // 16-byte chunks of one plane of a unit
+    constexpr int WCH = 2 * PCH;
+    constexpr int NWL = (WCH + 255) / 256;
+    static_assert(CIN % 32 == 0 && COUT % 16 == 0, "channel granularity");
+    static_assert(WCH % 256 == 0, "whole chunk rounds");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    _Float16 *Wb = reinterpret_cast<_Float16 *>(smem_raw);              // [2 buffers][2 planes][COUT][LDW]
+    int *nbr_s = reinterpret_cast<int *>(Wb + 4 * COUT * LDW);          // [TM][kvol]
+    float *red = reinterpret_cast<float *>(nbr_s + TM * 27);            // [4][COUT]
+    int *mask_s = reinterpret_cast<int *>(red + 4 * COUT);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int kvol = a.kvol;
+    int n = *a.count_out;
+    if (n > a.cap_out) n = a.cap_out;
+    const int row0 = (int)blockIdx.x * TM;
+    if (row0 >= n) return;
+    const auto rsrc_f = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, (int)a.codes_bytes, 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.wp, 0, kvol * COUT * 2 * CIN * 2, 0x00020000);
+
+    if (tid == 0) mask_s[0] = 0;
+    {
+        const int rows = n - row0 < TM ? n - row0 : TM;
+        const auto rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void *)(a.nbr + (size_t)row0 * kvol), 0, rows * kvol * 4, 0x00020000);
+        int v[(TM * 27 + 255) / 256];
+#pragma unroll
+        for (int i = 0; i < (TM * 27 + 255) / 256; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_n, (tid + 256 * i) * 4, 0, 0);
+        const int lim = rows * kvol;
+#pragma unroll
+        for (int i = 0; i < (TM * 27 + 255) / 256; ++i) {
+            const int t = tid + 256 * i;
+            if (t < TM * kvol) nbr_s[t] = t < lim ? v[i] : -1;
+        }
+    }
+    __syncthreads();
+    if (tid < TM) {
+        int bits = 0;
+        for (int k = 0; k < kvol; ++k)
+            if (nbr_s[tid * kvol + k] >= 0) bits |= 1 << k;
+        if (bits) atomicOr(&mask_s[0], bits);
+    }
+    __syncthreads();
+    const int live = mask_s[0];
+
+    f32x4 acc[RT][NT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    i32x4v A0[RT], A1[RT], wn[NWL];
+    // chunk t of a unit: plane = t / PCH, row o, 16-byte chunk c8 of the UC-channel slice
+    auto loadW = [&](int k, int h) {
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int t = tid + 256 * i;
+            const int pl = t / PCH, r = t % PCH;
+            const int c8 = r % (UC / 8), o = r / (UC / 8);
+            const unsigned off = (unsigned)((((k * COUT + o) * 2 + pl) * CIN + h * UC + c8 * 8) * 2);
+            wn[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0);       // k = kvol is past the end of the tensor: zeros
+        }
+    };
+    auto storeW = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < NWL; ++i) {
+            const int t = tid + 256 * i;
+            const int pl = t / PCH, r = t % PCH;
+            const int c8 = r % (UC / 8), o = r / (UC / 8);
+            *reinterpret_cast<i32x4v *>(Wb + ((b * 2 + pl) * COUT + o) * LDW + (SWZ ? (c8 ^ ((o >> 1) & 7)) : c8) * 8) = wn[i];
+        }
+    };
+    auto readSrc = [&](int (&src)[RT], int k) {
+        const int kk = k < kvol ? k : 0;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const int v = nbr_s[(wave * (RT * 16) + rt * 16 + l15) * kvol + kk];
+            src[rt] = k < kvol ? v : -1;
+        }
+    };
+    auto loadA1 = [&](i32x4v (&A)[RT], const int (&src)[RT], int h, int rt) {
+        if (UC == 64) {
+            const unsigned off = src[rt] >= 0 ? (unsigned)src[rt] * (unsigned)CIN + (unsigned)(h * 64 + 16 * g) : CD_OOB;
+            A[rt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, off, 0, 0);
+        } else {
+            const unsigned off = src[rt] >= 0 ? (unsigned)src[rt] * (unsigned)CIN + (unsigned)(8 * g) : CD_OOB;
+            const i32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrc_f, off, 0, 0);
+            A[rt] = (i32x4v){v.x, v.y, 0, 0};
+        }
+    };
+    auto loadA = [&](i32x4v (&A)[RT], int k, int h) {
+        int src[RT];
+        readSrc(src, k);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) loadA1(A, src, h, rt);
+    };
+    auto next_unit = [&](int &k, int &h) {
+        if (k >= kvol) return;
+        if (h + 1 < NU) { ++h; return; }
+        h = 0;
+        const int rest = live & ~((2 << k) - 1);
+        k = rest ? (__ffs(rest) - 1) : kvol;
+    };
+    auto unit = [&](i32x4v (&Acur)[RT], i32x4v (&Anext)[RT], int b, int &k, int &h) {
+        next_unit(k, h);                                 // (k, h) now names the NEXT unit
+        loadW(k, h);
+        f16x8 F[RT][KC];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            F[rt][0] = cd_cvt8(Acur[rt].x, Acur[rt].y);
+            if (KC == 2) F[rt][KC - 1] = cd_cvt8(Acur[rt].z, Acur[rt].w);
+        }
+        // fragment j = (kc * NT + nt) * 2 + plane: read FD ahead of the MFMAs that use it, each feeds RT MFMAs
+        constexpr int NF = KC * NT * 2;
+        constexpr int FD = 4;
+        const int c0 = SWZ ? (g ^ ((l15 >> 1) & 7)) : g;
+        const _Float16 *bb = Wb + (b * 2 * COUT + l15) * LDW;
+        auto frag = [&](int j) {
+            const int pl = j & 1, nt = (j >> 1) % NT, kc = (j >> 1) / NT;
+            const int c = SWZ ? (c0 ^ (kc * 4)) : (c0 + kc * 4);
+            return *reinterpret_cast<const f16x8 *>(bb + (pl * COUT + nt * 16) * LDW + c * 8);
+        };
+        f16x8 fb[FD + 1];
+#pragma unroll
+        for (int j = 0; j < FD && j < NF; ++j) fb[j] = frag(j);
+        int src[RT];
+        readSrc(src, k);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+            if (j + FD < NF) fb[(j + FD) % (FD + 1)] = frag(j + FD);
+            if (j >= 1 && j <= RT) loadA1(Anext, src, h, j - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int nt = (j >> 1) % NT, kc = (j >> 1) / NT;
+            const f16x8 f = fb[j % (FD + 1)];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F[rt][kc], f, acc[rt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        storeW(b ^ 1);
+        __syncthreads();
+    };
+
+    int k = live ? (__ffs(live) - 1) : kvol, h = 0;
+    const int nunits = __popc(live) * NU;
+    loadW(k, h);
+    loadA(A0, k, h);
+    storeW(0);
+    __syncthreads();
+    for (int u = 0; u < nunits; u += 2) {
+        unit(A0, A1, 0, k, h);
+        unit(A1, A0, 1, k, h);
+    }
+
+    // ---- epilogue (D layout: col = lane&15 -> out channel, row = 4g + reg -> tile row)
+    int mrow[RT][4];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int tr = row0 + wave * (RT * 16) + rt * 16 + 4 * g + r;
+            mrow[rt][r] = tr < n ? (a.perm ? a.perm[tr] : tr) : -1;
+        }
+    float cmax[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int o = nt * 16 + l15;
+        const float mul = a.out_mul[o];
+        const float bs = a.bias ? a.bias[o] : 0.f;
+        const float ps = a.post_scale ? a.post_scale[o] : 1.f;
+        const float pt = a.post_shift ? a.post_shift[o] : 0.f;
+        float mx = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mrow[rt][r];
+                if (m >= 0) {
+                    float v = __fmul_rn(acc[rt][nt][r], mul);
+                    if (a.bias) v = __fadd_rn(v, bs);
+                    if (a.post_scale) v = __fadd_rn(__fmul_rn(v, ps), pt);
+                    if (a.residual) v = __fadd_rn(v, a.residual[(size_t)m * COUT + o]);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.feats_out[(size_t)m * COUT + o] = v;
+                    mx = fmaxf(mx, fabsf(v));
+                }
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        cmax[nt] = mx;
+    }
+    if (a.absmax_out) {
+        if (g == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) red[wave * COUT + nt * 16 + l15] = cmax[nt];
+        }
+        __syncthreads();
+        for (int o = tid; o < COUT; o += 256) {
+            const float mx = fmaxf(fmaxf(red[o], red[COUT + o]), fmaxf(red[2 * COUT + o], red[3 * COUT + o]));
+            if (mx > a.absmax_out[o]) aq3d_atomic_max_pos(&a.absmax_out[o], mx);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ host side
+template <int COUT, int KVOL, int NW>
+static int launch_cd(const SpCodedArgs &a, hipStream_t stream) {
+    constexpr int NCH = (KVOL * 16 + 31) / 32;
+    constexpr size_t lds = (size_t)2 * COUT * (NCH * 32 + 8) * 2 + NW * COUT * 4;
+    const int tiles = aq3d_div_up(a.cap_out, 16 * NW);
+    const int grid = tiles < 2048 ? (tiles < 1 ? 1 : tiles) : 2048;
+    auto kern = spconv_cd_kernel<COUT, KVOL, NW>;
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
+    AQ3D_CHECK_LAUNCH("aq3d_spconv_coded(direct)");
+    return AQ3D_OK;
+}
+
+template <int CIN, int COUT>
+static int launch_cw(const SpCodedArgs &a, hipStream_t stream) {
+    constexpr int UC = CIN < 64 ? CIN : 64;
+    constexpr size_t lds = (size_t)4 * COUT * (UC == 64 ? UC : UC + 8) * 2 + (size_t)128 * 27 * 4 + (size_t)4 * COUT * 4 + 64;
+    const int grid = aq3d_div_up(a.cap_out, 128);
+    auto kern = spconv_cw_kernel<CIN, COUT>;
+    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3(grid < 1 ? 1 : grid), dim3(256), lds, stream, a);
+    AQ3D_CHECK_LAUNCH("aq3d_spconv_coded(wide)");
+    return AQ3D_OK;
+}
+
+extern "C" int aq3d_spconv_coded_supported(int32_t cin, int32_t cout, int32_t kvol) {
+    if (kvol < 1 || kvol > 27) return 0;
+    if (cin == 16) return kvol == 27 && (cout == 16 || cout == 32);
+    return (cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && (cout == 64 || cout == 128)) || (cin == 128 && cout == 128);
+}
+
+extern "C" size_t aq3d_spconv_wprep_bytes(int32_t cin, int32_t cout, int32_t kvol) {
+    return (size_t)kvol * cout * 2 * cin * sizeof(_Float16);
+}
+
+extern "C" int aq3d_spconv_prep(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C, int32_t bits,
+                                int32_t per_tensor, const int8_t *weight_codes, const float *w_dequant, int32_t kvol,
+                                int32_t cout, int8_t *codes_out, void *wprep_out, float *out_mul_out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(x && amax && count && weight_codes && w_dequant && codes_out && wprep_out && out_mul_out, "aq3d_spconv_prep: null argument");
+    AQ3D_REQUIRE(C >= 16 && C <= 256 && (C & 15) == 0 && bits >= 2 && bits <= 8, "aq3d_spconv_prep: C=%d bits=%d", C, bits);
+    AQ3D_REQUIRE(cap > 0 && kvol >= 1 && kvol <= 27 && cout >= 1, "aq3d_spconv_prep: cap=%d kvol=%d cout=%d", cap, kvol, cout);
+    AQ3D_REQUIRE((long long)cap * C < (1ll << 31), "aq3d_spconv_prep: cap * C overflows 32-bit indexing");
+    SpPrepArgs a;
+    a.x = x; a.amax = amax; a.count = count; a.cap = cap; a.C = C; a.qmax = (float)((1 << (bits - 1)) - 1);
+    a.per_tensor = per_tensor; a.codes = codes_out; a.w = weight_codes; a.w_dequant = w_dequant; a.wp = (_Float16 *)wprep_out;
+    a.out_mul = out_mul_out; a.kvol = kvol; a.cout = cout;
+    a.row_blocks = aq3d_grid((int64_t)cap * C / 4, 256);
+    const int wblocks = aq3d_grid((int64_t)kvol * cout * C / 8, 256, 256);
+    hipLaunchKernelGGL(sp_prep_kernel, dim3(a.row_blocks + wblocks), dim3(256), 0, stream, a);
+    AQ3D_CHECK_LAUNCH("aq3d_spconv_prep");
+    return AQ3D_OK;
+}
+
+extern "C" int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void *wprep, const float *out_mul, const float *bias,
+                                 const float *post_scale, const float *post_shift, const float *residual, const int32_t *nbr,
+                                 const int32_t *perm, const int32_t *count_out, int32_t cap_out, int32_t cin, int32_t cout,
+                                 int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(codes && wprep && out_mul && nbr && count_out && feats_out, "aq3d_spconv_coded: null argument");
+    AQ3D_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "aq3d_spconv_coded: post_scale/post_shift must come together");
+    AQ3D_REQUIRE(cap_in > 0 && cap_out > 0 && (long long)cap_in * cin < (1ll << 31), "aq3d_spconv_coded: cap_in=%d cap_out=%d", cap_in, cap_out);
+    if (!aq3d_spconv_coded_supported(cin, cout, kvol)) {
+        aq3d_set_error("aq3d_spconv_coded: unsupported shape cin=%d cout=%d kvol=%d", cin, cout, kvol);
+        return AQ3D_ERR_UNSUPPORTED;
+    }
+    SpCodedArgs a;
+    a.codes = codes; a.wp = (const _Float16 *)wprep; a.out_mul = out_mul; a.bias = bias; a.post_scale = post_scale;
+    a.post_shift = post_shift; a.residual = residual; a.nbr = nbr; a.perm = perm; a.count_out = count_out;
+    a.feats_out = feats_out; a.absmax_out = absmax_out; a.cap_out = cap_out; a.kvol = kvol;
+    a.relu = (flags & AQ3D_FLAG_RELU) ? 1 : 0;
+    a.codes_bytes = (unsigned)((int64_t)cap_in * cin);
+    if (cin == 16 && cout == 16) return launch_cd<16, 27, 4>(a, stream);
+    if (cin == 16 && cout == 32) return launch_cd<32, 27, 4>(a, stream);
+    if (cin == 32 && cout == 32) return launch_cw<32, 32>(a, stream);
+    if (cin == 32 && cout == 64) return launch_cw<32, 64>(a, stream);
+    if (cin == 64 && cout == 64) return launch_cw<64, 64>(a, stream);
+    if (cin == 64 && cout == 128) return launch_cw<64, 128>(a, stream);
+    if (cin == 128 && cout == 128) return launch_cw<128, 128>(a, stream);
+    return AQ3D_ERR_UNSUPPORTED;
+}

@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class Aq3dError(RuntimeError):
@@ -72,6 +72,10 @@ SIGNATURES = {
     "aq3d_quantize_rows": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, P, P, P, P, P]),
     "aq3d_spconv": (c_int32, [P, c_int32, P, P, c_int32, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32,
                               c_int32, P, P, P]),
+    "aq3d_spconv_coded_supported": (c_int32, [c_int32, c_int32, c_int32]),
+    "aq3d_spconv_wprep_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "aq3d_spconv_prep": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, P, P, c_int32, c_int32, P, P, P, P]),
+    "aq3d_spconv_coded": (c_int32, [P, c_int32, P, P, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P]),
     "aq3d_scatter_dense": (c_int32, [P, P, P, c_int32, c_int32, I3, c_int32, P, P]),
     "aq3d_piece_absmax": (c_int32, [P, c_int32, c_int32, c_int32, c_int32, P, P]),
     "aq3d_sq_param_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

@@ -189,6 +189,43 @@ def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequan
     return y
 
 
+def spconv_coded_supported(cin, cout, kvol):
+    return bool(_lib.load().aq3d_spconv_coded_supported(int(cin), int(cout), int(kvol)))
+
+
+def spconv_prep(x, amax, count, weight_codes, w_dequant, bits=8, per_tensor=False, out=None):
+    """Quantiser + per-frame weight copy of one QConvNd layer in ONE launch (aq3d_spconv_prep).
+    x f32 [cap, C]; weight_codes i8 [kvol, cout, C] → (codes i8 [cap, C], wprep f16 [kvol, cout, 2, C], out_mul f32 [cout])."""
+    L = _lib.load()
+    cap, C = x.shape
+    kvol, cout, cin = weight_codes.shape
+    assert cin == C and weight_codes.dtype == torch.int8
+    if out is None:
+        codes = torch.zeros((cap, C), dtype=torch.int8, device=x.device)
+        wprep = torch.empty((kvol, cout, 2, C), dtype=torch.float16, device=x.device)
+        out_mul = torch.empty((cout,), dtype=f32, device=x.device)
+    else:
+        codes, wprep, out_mul = out
+    check(L.aq3d_spconv_prep(_p(x), _p(amax), _p(count), cap, C, int(bits), int(bool(per_tensor)), _p(weight_codes),
+                             _p(w_dequant), kvol, cout, _p(codes), _p(wprep), _p(out_mul), _stream()), "aq3d_spconv_prep")
+    return codes, wprep, out_mul
+
+
+def spconv_coded(codes, wprep, out_mul, nbr, count_out, *, perm=None, bias=None, post_scale=None, post_shift=None,
+                 residual=None, relu=False, absmax_out=None, out=None):
+    """Gather-GEMM on int8-coded activations (aq3d_spconv_coded). codes i8 [cap_in, cin]; wprep f16 [kvol, cout, 2, cin]."""
+    L = _lib.load()
+    cap_out, kvol = nbr.shape
+    cap_in, cin = codes.shape
+    cout = wprep.shape[1]
+    assert tuple(wprep.shape) == (kvol, cout, 2, cin), (tuple(wprep.shape), (kvol, cout, 2, cin))
+    y = out if out is not None else torch.empty((cap_out, cout), dtype=f32, device=nbr.device)
+    check(L.aq3d_spconv_coded(_p(codes), cap_in, _p(wprep), _p(out_mul), _p(bias), _p(post_scale), _p(post_shift), _p(residual),
+                              _p(nbr), _p(perm), _p(count_out), cap_out, cin, cout, kvol, FLAG_RELU if relu else 0, _p(y),
+                              _p(absmax_out), _stream()), "aq3d_spconv_coded")
+    return y
+
+
 def spconv_workspace(cap_out, cout, device):
     """Zeroed scratch for spconv(workspace=...): lets the wide kernel split a tile's offsets over two workgroups."""
     return torch.zeros((_lib.load().aq3d_spconv_workspace_bytes(int(cap_out), int(cout)),), dtype=torch.uint8, device=device)

@@ -7,7 +7,7 @@ OUT = os.path.join(HERE, "libaq3d_diag.so")
 
 def build():
     cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-fno-fast-math", "-ffp-contract=off",
-           os.path.join(HERE, "nms_diag.hip"), "-o", OUT]
+           os.path.join(HERE, "nms_diag.hip"), os.path.join(HERE, "op_probe.hip"), "-o", OUT]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(r.stdout + r.stderr)

@@ -171,6 +171,13 @@ def test_subm_layer_30k(dev, w150k, C):
     print("SubM %d->%d @ %d voxels, %d pairs: max err %.3e of the output scale" % (C, C, m, int((nbr_ref >= 0).sum()), err))
     assert err <= TOL_LAYER
     np.testing.assert_allclose(am_out.cpu().numpy(), np.abs(ref).max(axis=0), rtol=0, atol=TOL_LAYER * max(1.0, float(np.abs(ref).max())))
+    # production path: int8-coded gather, scale folded into the per-frame weight copy
+    wk8 = torch.from_numpy(np.ascontiguousarray(codes.reshape(C, 27, C).transpose(1, 0, 2)).astype(np.int8)).to(dev)
+    cds, wprep, out_mul = ops.spconv_prep(xd, amax, count, wk8, wdq)
+    y2 = ops.spconv_coded(cds, wprep, out_mul, nbr, count, bias=torch.from_numpy(bias).to(dev), relu=True)
+    err2 = np.abs(y2[:m].cpu().numpy() - ref).max() / max(1.0, float(np.abs(ref).max()))
+    print("   coded path: max err %.3e" % err2)
+    assert err2 <= TOL_LAYER
 
 
 # ------------------------------------------------------------------ configs[4]: VoxelNeXt on S40k

@@ -183,3 +183,69 @@ def test_spconv_int8_codes(dev, cin, cout):
     wk_fq = torch.from_numpy(np.ascontiguousarray(wq.reshape(cout, 27, cin).transpose(1, 0, 2))).to(dev)
     y2 = ops.spconv(fq, wk_fq, nbr, count, cout)[:m].cpu().numpy()
     assert np.abs(y2 - ref).max() <= tol
+
+
+def _code_positions(C):
+    """Byte position of channel c in a code row written by aq3d_spconv_prep (csrc/spconv_coded.hip::cd_code_pos)."""
+    c = np.arange(C)
+    if C < 64:
+        return c
+    w = c & 63
+    return (c >> 6 << 6) + 16 * ((w & 31) >> 3) + 8 * (w >> 5) + (w & 7)
+
+
+@pytest.mark.parametrize("cin,cout,ksize", [(16, 16, (3, 3, 3)), (16, 32, (3, 3, 3)), (32, 32, (3, 3, 3)), (32, 64, (3, 3, 3)),
+                                            (64, 64, (3, 3, 3)), (64, 128, (3, 3, 3)), (128, 128, (3, 3, 3)), (128, 128, (3, 1, 1)),
+                                            (128, 128, (1, 3, 3))])
+@pytest.mark.parametrize("per_tensor", [False, True])
+def test_spconv_coded_vs_oracle(dev, cin, cout, ksize, per_tensor):
+    """Production path of the QConvNd layers: aq3d_spconv_prep (codes bit-exact + per-frame weight copy) + aq3d_spconv_coded,
+    full epilogue, with and without a tile-order permutation; a dead input channel and rows without any neighbour included."""
+    from amdq3d import ops
+    if per_tensor and (cin, cout) not in ((16, 16), (64, 64)):
+        pytest.skip("per-tensor recipe: two shapes are enough")
+    kvol = int(np.prod(ksize))
+    idx, shape = _sparse_input(dev, m_pts=2500, seed=cin + cout, batch=1)
+    m = len(idx)
+    rng = np.random.default_rng(cout * 3 + kvol)
+    feats = np.maximum(rng.normal(0, 1, (m, cin)), 0).astype(np.float32) * rng.uniform(0.05, 6, cin).astype(np.float32)
+    feats[:, 3] = 0                                                       # dead channel: amax 0 -> scale 0 / divide 1
+    feats[:, 5] *= 1e-6                                                   # tiny channel
+    w = (rng.normal(0, 1, (cout,) + ksize + (cin,)) / np.sqrt(kvol * cin)).astype(np.float32)
+    bias = rng.normal(0, 0.1, cout).astype(np.float32)
+    ps = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    pt = rng.normal(0, 0.1, cout).astype(np.float32)
+    res = rng.normal(0, 1, (m, cout)).astype(np.float32)
+    wq, wcodes, wdiv = OS.qconv_weight(w, 8)
+    aq, _ = OS.qconv_act(feats, 8, cw=not per_tensor)
+    nbr_ref = OS.subm_neighbors(idx, shape, ksize)
+    ref = np.maximum(OS.gather_conv(aq, wq, nbr_ref, bias) * ps + pt + res, 0)
+    cap = m + 41
+    count = torch.tensor([m], dtype=torch.int32, device=dev)
+    fin = torch.zeros((cap, cin), device=dev); fin[:m] = torch.from_numpy(feats).to(dev)
+    rs = torch.zeros((cap, cout), device=dev); rs[:m] = torch.from_numpy(res).to(dev)
+    amax = ops.absmax_cols(fin, count)
+    wk = torch.from_numpy(np.ascontiguousarray(wcodes.reshape(cout, kvol, cin).transpose(1, 0, 2)).astype(np.int8)).to(dev)
+    wdq = torch.from_numpy((np.float32(1.0) / wdiv).astype(np.float32)).to(dev)
+    codes, wprep, out_mul = ops.spconv_prep(fin, amax, count, wk, wdq, bits=8, per_tensor=per_tensor)
+    # codes are the quantiser's integers, bit-exact (aq3d_quantize_rows is the pinned reference for them)
+    codes_ref, _, _ = ops.quantize_rows(fin, amax, count, bits=8, per_tensor=per_tensor, want_codes=True)
+    np.testing.assert_array_equal(codes[:m].cpu().numpy()[:, _code_positions(cin)], codes_ref[:m].cpu().numpy())
+    tol = 2e-5 * max(1.0, np.abs(ref).max())
+    kw = dict(bias=torch.from_numpy(bias).to(dev), post_scale=torch.from_numpy(ps).to(dev), post_shift=torch.from_numpy(pt).to(dev),
+              residual=rs, relu=True)
+    nbr = torch.full((cap, kvol), -1, dtype=torch.int32, device=dev)
+    nbr[:m] = torch.from_numpy(nbr_ref).to(dev)
+    am = torch.zeros((cout,), device=dev)
+    y = ops.spconv_coded(codes, wprep, out_mul, nbr, count, absmax_out=am, **kw)[:m].cpu().numpy()
+    assert np.abs(y - ref).max() <= tol, np.abs(y - ref).max() / max(1.0, np.abs(ref).max())
+    np.testing.assert_array_equal(am.cpu().numpy(), np.abs(y).max(axis=0))
+    # tile order = a permutation of the output rows (gather table given in tile order): identical values, row for row
+    perm = rng.permutation(m).astype(np.int32)
+    nbr_p = torch.full((cap, kvol), -1, dtype=torch.int32, device=dev)
+    nbr_p[:m] = torch.from_numpy(nbr_ref[perm]).to(dev)
+    perm_d = torch.zeros((cap,), dtype=torch.int32, device=dev)
+    perm_d[:m] = torch.from_numpy(perm).to(dev)
+    y2 = torch.zeros((cap, cout), device=dev)
+    ops.spconv_coded(codes, wprep, out_mul, nbr_p, count, perm=perm_d, out=y2, **kw)
+    np.testing.assert_array_equal(y2[:m].cpu().numpy(), y)
