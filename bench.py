@@ -5,9 +5,12 @@ Waymo-shape frames (150 000 points / 30 000 voxels), one frame per step per GPU,
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-Rank 0 prints ONE JSON line (metric/value/unit/... + "roofline" + "cpu_baseline").
-A step = one pass of the whole hot path (voxelize → sparse backbone → BEV backbone → head → decode → NMS) over one
-frame, including the single device→host read of the detection counts that ends Detector.forward.
+Rank 0 prints ONE JSON line: metric/value/unit/... + "roofline" (dominant kernel family) + "roofline_by_kernel" (every
+family) + "accuracy" (int8 engine vs the fp32 oracle, the offline stand-in for "mAP delta vs fp32 ref") +
+"cpu_baseline" — see DESIGN.md §7. A step = one pass of the whole hot path (voxelize → sparse backbone → BEV backbone →
+head → decode → NMS) over one frame, including the device→host read of the detection counts that ends Detector.forward.
+`value` is a THROUGHPUT with `--inflight` frames sharing the chip (default: one per device plan); the single-frame
+latency is reported beside it (`latency_ms_single_frame`).
 """
 import argparse
 import collections
@@ -35,16 +38,23 @@ WORKLOADS = {      # --workload → (cfg, points, voxels, description); the head
 }
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_PEAK_TOPS = {"i8": 5000.0, "f16": 2500.0, "f32": 157.3}   # dense peaks: int8 = 2x f16/bf16 (2.5 PF); f32 MFMA = vector rate
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12                   # 256 CUs x 4 SIMD16 x 2.4 GHz: one fp32 VALU op per lane and clock
+I8_QUANT_OPS_PER_ELEM = 6        # SQConv2d quantise-while-staging: reciprocal multiply, Markstein fix-up (2), rint, clamp (2)
 
 
-def build(cfg_path, dev, n_points=N_POINTS, n_voxels=N_VOXELS):
+def rank_seed0(rank):
+    """Every rank works on its own 8 distinct frames, so N = 1 and N = 8 do the same per-GPU work."""
+    return 4 + N_FRAMES * int(rank)
+
+
+def build(cfg_path, dev, n_points=N_POINTS, n_voxels=N_VOXELS, seed0=4, static=False):
     from amdq3d import quant
     from amdq3d.config import AttrDict, cfg_from_yaml_file
     from amdq3d.datasets import SyntheticDataset
     from amdq3d.detector import build_network
     from amdq3d.synthetic import init_synthetic_weights
     cfg = cfg_from_yaml_file(cfg_path, AttrDict())
-    ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_frames=N_FRAMES, n_points=n_points, n_voxels=n_voxels, seed0=4)
+    ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_frames=N_FRAMES, n_points=n_points, n_voxels=n_voxels, seed0=seed0)
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
     init_synthetic_weights(model, 4)
     model.eval()
@@ -59,11 +69,9 @@ def build(cfg_path, dev, n_points=N_POINTS, n_voxels=N_VOXELS):
 
 
 def kernel_work(eng, cat):
-    """Algorithmic work of ONE frame for a timed category: (bytes, ops, n_launches). Per-unit figures: DESIGN.md §Kernels."""
+    """Algorithmic work of ONE frame for a timed category: (bytes, ops, n_launches). Per-unit figures: DESIGN.md §3."""
     if cat == "conv2d_i8":
-        ops = 0
-        byts = 0
-        n = 0
+        ops = byts = n = 0
         for r in eng.dense_convs:
             if r["kind"] != "i8":
                 continue
@@ -95,8 +103,7 @@ def kernel_work(eng, cat):
             m_out, m_in = int(lv_out["count"].item()), int(lv_in["count"].item())
             nbr = eng._nbr_of(r["nbr"], r["level"])[:m_out]
             pairs = int((nbr >= 0).sum().item())
-            # algorithmic activation bytes: the int8 code of the quantised input (1 B) or fp32 (4 B) — what the layer needs,
-            # not what the chosen staging format (fp16 hi/lo pair) moves
+            # algorithmic activation bytes: the int8 code of the quantised input (1 B) or fp32 (4 B) — what the layer needs
             abytes = 1 if r["quant"] is not None and r["quant"]["on"] and r["quant"]["use_codes"] else 4
             wbytes = 1 if r["w_dequant"] is not None else 4
             ops += 2 * pairs * r["cin"] * r["cout"]
@@ -104,24 +111,146 @@ def kernel_work(eng, cat):
                 + m_out * r["kvol"] * 4 + (m_out * r["cout"] * 4 if r["residual"] is not None else 0)
             n += 1
         return byts, ops, n
+    if cat in ("quantize_rows", "sp_prep"):
+        byts = n = 0
+        for r in eng.sparse_convs:
+            if r["quant"] is None or not r["quant"]["on"]:
+                continue
+            m_in = int(eng.levels[r["x"]["level"]]["count"].item())
+            byts += m_in * r["cin"] * 5          # fp32 in, int8 code out
+            n += 1
+        return byts, 0, n
+    if cat == "voxelize":
+        m = int(eng.levels[0]["count"].item())
+        c = eng.num_point_features
+        return N_POINTS * c * 4 + m * (16 + 4 * c), 0, 1
+    if cat == "scatter_dense" and not eng.fully_sparse:
+        D, H, W = eng.bev_shape
+        m = int(eng.levels[eng.encoded[1]]["count"].item())
+        c = eng.encoded[0]["C"]
+        return D * H * W * c * 4 + m * c * 4, 0, 1
+    if cat == "piece_absmax":
+        byts = n = 0
+        for r in eng.dense_convs:
+            if r["kind"] == "i8" and r["pieces_owner"]:
+                g = r["geom"]
+                byts += g.H * g.W * g.Cin * 4
+                n += 1
+        return byts, 0, n
+    if cat == "rulebook":
+        byts = 0
+        for lv in eng.levels:
+            m = int(lv["count"].item())
+            byts += m * 16 + m * lv["nbr"].shape[1] * 4 + (m * lv["down"]["nbr"].shape[1] * 4 if "down" in lv else 0)
+        return byts, 0, len(eng.levels)
     return 0, 0, 0
 
 
-def cpu_baseline(cfg, ds, state):
-    """The CPU oracle (a port, not the reference binary) on ONE frame of the same workload, host cores of this box."""
-    pts = ds[0]["points"]
-    t0 = time.time()
+def family_roofline(eng, cat, ms_per_frame, traffic):
+    """Roofline record of one kernel family from its event-timed milliseconds per frame."""
+    byts, ops, n = kernel_work(eng, cat)
+    if n == 0 or ms_per_frame <= 0:
+        return None
+    avg_s = ms_per_frame * 1e-3 / n
+    gbs = byts / n / avg_s / 1e9
+    rec = {"kernel": cat, "launches_per_frame": n, "avg_launch_us": avg_s * 1e6, "ms_per_frame": ms_per_frame,
+           "algorithmic_bytes_per_launch": byts / n, "traffic": traffic.get(cat)}
+    if cat == "conv2d_i8":
+        ach = ops / n / avg_s / 1e12
+        q_ops = sum(r["geom"].H * r["geom"].W * r["geom"].Cin * r["geom"].ksize ** 2 * I8_QUANT_OPS_PER_ELEM
+                    for r in eng.dense_convs if r["kind"] == "i8")
+        valu_s = q_ops / (VALU_PEAK_TOPS * 1e12)
+        rec.update({"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TOPS["i8"], "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TOPS["i8"],
+                    "hbm_GBps_algorithmic": gbs, "frac_hbm": gbs / HBM_PEAK_GBS,
+                    "valu_quantise_bound": {"ops_per_frame": q_ops, "ops_per_element_and_tap": I8_QUANT_OPS_PER_ELEM,
+                                            "peak_TOPs": VALU_PEAK_TOPS, "bound_ms_per_frame": valu_s * 1e3,
+                                            "frac": valu_s * 1e3 / ms_per_frame}})
+    elif cat == "conv2d_f32":
+        ach = ops / n / avg_s / 1e12       # three fp16 MFMAs per fp32 product (hi*hi, hi*lo, lo*hi): priced against the fp16 pipe
+        rec.update({"bound": "mfma", "achieved": 3 * ach, "peak": MFMA_PEAK_TOPS["f16"], "unit": "TFLOP/s",
+                    "frac": 3 * ach / MFMA_PEAK_TOPS["f16"], "useful_TFLOPs_fp32": ach, "hbm_GBps_algorithmic": gbs,
+                    "frac_hbm": gbs / HBM_PEAK_GBS})
+    elif cat.startswith("spconv_c"):
+        tfs = ops / n / avg_s / 1e12       # useful flops; the hi|lo weight pair costs two fp16 MFMAs per product
+        ridge = MFMA_PEAK_TOPS["f16"] * 1e12 / 2 / (HBM_PEAK_GBS * 1e9)
+        if byts > 0 and ops / byts > ridge:
+            rec.update({"bound": "mfma", "achieved": 2 * tfs, "peak": MFMA_PEAK_TOPS["f16"], "unit": "TFLOP/s",
+                        "frac": 2 * tfs / MFMA_PEAK_TOPS["f16"], "useful_TFLOPs": tfs, "hbm_GBps_algorithmic": gbs, "frac_hbm": gbs / HBM_PEAK_GBS})
+        else:
+            rec.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "useful_TFLOPs": tfs})
+        rec["intensity_flop_per_byte"] = ops / byts if byts else None
+    else:
+        rec.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
+    return rec
+
+
+def cpu_baseline(cfg, ds, state, frames=2, warm=1, threads=None):
+    """The CPU oracle (a port, not the reference binary) on the same workload, host cores of this box: `warm` untimed +
+    `frames` timed frames, median. SURVEY §8d's full protocol (T in {1, all}, 3 + 10 frames) is `--cpu-frames 10 --cpu-warm 3`
+    run twice with `--cpu-threads`; the default is a bounded sample so that the bench stays within minutes."""
+    if threads:
+        torch.set_num_threads(int(threads))
     if cfg.MODEL.NAME == "VoxelNeXt":
         from oracle import voxelnext as OV
-        b, s, l = OV.run(state, cfg, pts, OV.Recipe(8, 8, True))
-        name = "oracle.voxelnext.run"
+        run, name = (lambda p: OV.run(state, cfg, p, OV.Recipe(8, 8, True))), "oracle.voxelnext.run"
     else:
         from oracle import centerpoint as OC
-        b, s, l = OC.run(state, cfg, pts, OC.Recipe(8, 8, True, 0.5))
-        name = "oracle.centerpoint.run"
-    dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
-            "sample": "1 frame (%d pts) through %s, %.1f s, %d boxes" % (len(pts), name, dt, len(s))}
+        run, name = (lambda p: OC.run(state, cfg, p, OC.Recipe(8, 8, True, 0.5))), "oracle.centerpoint.run"
+    times, nb = [], 0
+    for i in range(warm + frames):
+        pts = ds[i % len(ds)]["points"]
+        t0 = time.time()
+        b, s, l = run(pts)
+        if i >= warm:
+            times.append(time.time() - t0)
+            nb = len(s)
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": "%d warm-up + %d timed frames (%d pts) through %s, median %.1f s/frame (all: %s), %d boxes in the last one"
+                      % (warm, frames, len(pts), name, med, ", ".join("%.1f" % t for t in times), nb)}
+
+
+def accuracy_proxy(cfg, ds, state, model, batches, n_frames):
+    """SURVEY §8c, last row — the offline stand-in for "mAP delta vs fp32 ref": detections of the int8 engine against the fp32
+    restatement (oracle, recipe=None) on the seeded frames: recall / precision of matched boxes at BEV IoU 0.7 (same label)
+    and the mean |score difference| of the matched pairs. Reported as a proxy, never as mAP."""
+    from oracle import decode as OD
+    if cfg.MODEL.NAME == "VoxelNeXt":
+        from oracle import voxelnext as OV
+        ref_run = lambda p: OV.run(state, cfg, p, None)
+    else:
+        from oracle import centerpoint as OC
+        ref_run = lambda p: OC.run(state, cfg, p, None)
+    n_ref = n_det = tp_ref = tp_det = 0
+    dscore = []
+    t0 = time.time()
+    for i in range(n_frames):
+        b_ref, s_ref, l_ref = ref_run(ds[i]["points"])
+        with torch.no_grad():
+            pred, _ = model(dict(batches[i]))
+        pb = pred[0]["pred_boxes"].cpu().numpy()
+        ps = pred[0]["pred_scores"].cpu().numpy()
+        pl = pred[0]["pred_labels"].cpu().numpy()
+        n_ref += len(s_ref)
+        n_det += len(ps)
+        if len(s_ref) == 0 or len(ps) == 0:
+            continue
+        iou = OD.iou_bev(b_ref[:, :7], pb[:, :7]) * (l_ref[:, None] == pl[None, :])
+        best = iou.argmax(axis=1)
+        hit = iou[np.arange(len(s_ref)), best] >= 0.7
+        tp_ref += int(hit.sum())
+        tp_det += int((iou.max(axis=0) >= 0.7).sum())
+        dscore.extend(np.abs(s_ref[hit] - ps[best[hit]]).tolist())
+    return {"reference": "fp32 oracle (recipe=None), same seeded weights and frames", "frames": n_frames, "iou_threshold": 0.7,
+            "boxes_fp32": n_ref, "boxes_int8": n_det, "recall_of_fp32_boxes": tp_ref / max(n_ref, 1),
+            "precision_of_int8_boxes": tp_det / max(n_det, 1), "mean_abs_score_diff_matched": float(np.mean(dscore)) if dscore else None,
+            "note": "mAP proxy on synthetic frames with random weights (no dataset / checkpoint in the image); not mAP",
+            "seconds": time.time() - t0}
+
+
+def pct(v, q):
+    return float(np.percentile(np.asarray(v, dtype=np.float64), q)) if len(v) else None
 
 
 def main():
@@ -131,9 +260,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="centerpoint", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-accuracy", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--cpu-warm", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="torch/BLAS threads of the CPU baseline (0 = all host cores)")
     ap.add_argument("--inflight", type=int, default=0, help="frames enqueued before the oldest one is read back "
                     "(default: one per device plan of the detector — 4 for CenterPoint, 2 for VoxelNeXt)")
-    ap.add_argument("--breakdown", action="store_true", help="time every kernel family in an extra pass (stderr)")
     args = ap.parse_args()
 
     from amdq3d import dist as D
@@ -147,13 +279,14 @@ def main():
     D.init("nccl")
     lib.load()
     cfg_path, n_points, n_voxels, wl_desc = WORKLOADS[args.workload]
-    cfg, ds, model, state = build(cfg_path, dev, n_points, n_voxels)
+    cfg, ds, model, state = build(cfg_path, dev, n_points, n_voxels, seed0=rank_seed0(rank))
 
-    # frames resident in HBM before the timed region; frame i → rank i mod world
-    mine = D.frames_for_rank(max(N_FRAMES, world), rank, world) if world <= N_FRAMES else [rank % N_FRAMES]
-    batches = []
-    for i in mine:
-        b = ds.collate_batch([ds[i % N_FRAMES]])
+    # N_FRAMES distinct frames per rank, resident in HBM before the timed region (also kept in pinned host memory for the
+    # H2D-inclusive figure)
+    batches, host_pts = [], []
+    for i in range(N_FRAMES):
+        b = ds.collate_batch([ds[i]])
+        host_pts.append(torch.from_numpy(np.ascontiguousarray(b["points"])).pin_memory())
         load_data_to_gpu(b, dev)
         batches.append(b)
 
@@ -162,37 +295,69 @@ def main():
             return model(dict(batches[i % len(batches)]))
 
     eng = model.engine()
-    # warm-up: first pass times every kernel family to find the dominant one
+    # warm-up: first pass times every kernel family (eager launches, HIP events on the launch stream)
     eng.start_timing()
-    for i in range(max(args.warmup, 1)):
+    n_warm = max(args.warmup, 1)
+    for i in range(n_warm):
         step(i)
     warm = eng.stop_timing()
-    n_warm = max(args.warmup, 1)
     dominant = max(warm.items(), key=lambda kv: kv[1][1])[0] if warm else None
 
     if args.inflight <= 0:
         args.inflight = 4 if getattr(eng, "split_index", False) else 2
+
+    def run_pipelined(n_steps, get_batch, stamps=None):
+        n_det = 0
+        pending = collections.deque()
+        for i in range(n_steps):
+            with torch.no_grad():
+                pending.append(model.forward_async(get_batch(i)))
+            if len(pending) >= args.inflight:
+                n_det += int(pending.popleft().counts().sum())
+                if stamps is not None:
+                    stamps.append(time.perf_counter())
+        while pending:
+            n_det += int(pending.popleft().counts().sum())
+            if stamps is not None:
+                stamps.append(time.perf_counter())
+        return n_det
+
+    resident = lambda i: dict(batches[i % len(batches)])
     # graph warm-up (untimed): the first frames without per-kernel events capture the per-slot hipGraphs the timed region replays
-    with torch.no_grad():
-        for i in range(4 * eng.NSLOT * max(1, args.inflight)):
-            model.forward_async(dict(batches[i % len(batches)])).counts()
+    run_pipelined(4 * eng.NSLOT * max(1, args.inflight), resident)
     D.barrier()
     torch.cuda.synchronize(dev)
+    stamps = []
     t0 = time.perf_counter()
-    # two frames in flight: frame i+1 is enqueued before the detections of frame i are read back (every frame is still
-    # completed and read inside this region)
-    n_det = 0
-    pending = collections.deque()
-    for i in range(args.steps):
-        with torch.no_grad():
-            pending.append(model.forward_async(dict(batches[i % len(batches)])))
-        if len(pending) >= args.inflight:
-            n_det += int(pending.popleft().counts().sum())
-    while pending:
-        n_det += int(pending.popleft().counts().sum())
+    n_det = run_pipelined(args.steps, resident, stamps)
     torch.cuda.synchronize(dev)
     D.barrier()
     elapsed = time.perf_counter() - t0
+    total_frames, tmax, fps = D.aggregate_throughput(args.steps, elapsed, dev)
+    world_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+
+    # ---- everything below is outside the timed region
+    intervals_ms = [1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:])][args.inflight:]      # steady state: completion to completion
+    # single-frame latency: one frame in flight, enqueue → counts on the host
+    lat = []
+    for i in range(min(40, max(8, args.steps // 5))):
+        torch.cuda.synchronize(dev)
+        a = time.perf_counter()
+        with torch.no_grad():
+            model.forward_async(resident(i)).counts()
+        lat.append(1e3 * (time.perf_counter() - a))
+    # H2D-inclusive throughput: the 3 MB cloud comes from pinned host memory inside every step
+    def from_host(i):
+        p = host_pts[i % len(host_pts)].to(dev, non_blocking=True)
+        return {"points": p, "batch_size": 1, "frame_id": batches[i % len(batches)].get("frame_id")}
+    n_h2d = max(8, min(args.steps, 100))
+    run_pipelined(2 * args.inflight, from_host)
+    torch.cuda.synchronize(dev)
+    a = time.perf_counter()
+    run_pipelined(n_h2d, from_host)
+    torch.cuda.synchronize(dev)
+    fps_h2d = n_h2d / (time.perf_counter() - a)
+
     # roofline leg: the same frames once more with HIP events around every launch of the dominant kernel family (events cannot
     # bracket single kernels inside a replayed graph, so this pass enqueues eagerly; same kernels, same inputs, same stream)
     n_roof = max(1, min(args.steps, 50))
@@ -200,57 +365,52 @@ def main():
     for i in range(n_roof):
         step(i)
     timed = eng.stop_timing()
-    total_frames, tmax, fps = D.aggregate_throughput(args.steps, elapsed, dev)
 
     if rank == 0:
+        try:      # HBM bytes per launch measured with rocprofv3 --pmc in a separate run (profiles/pmc_traffic.json)
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+        except Exception:
+            traffic = {}
         roof = None
         if dominant and dominant in timed:
-            groups, ms = timed[dominant]
-            byts, ops, n_launch = kernel_work(eng, dominant)
-            per_frame_ms = ms / n_roof
-            avg_launch_s = per_frame_ms * 1e-3 / max(n_launch, 1)
-            if dominant == "conv2d_i8":
-                ach = ops / n_launch / avg_launch_s / 1e12
-                roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TOPS["i8"], "unit": "TFLOP/s",
-                        "frac": ach / MFMA_PEAK_TOPS["i8"], "traffic": None}
-            elif dominant == "conv2d_f32":
-                ach = ops / n_launch / avg_launch_s / 1e12
-                roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TOPS["f32"], "unit": "TFLOP/s",
-                        "frac": ach / MFMA_PEAK_TOPS["f32"], "traffic": None}
-            else:
-                # sparse conv family: bound by whichever roof its arithmetic intensity puts it under
-                gbs = byts / max(n_launch, 1) / avg_launch_s / 1e9 if n_launch else 0.0
-                tfs = ops / max(n_launch, 1) / avg_launch_s / 1e12 if n_launch else 0.0
-                ridge = MFMA_PEAK_TOPS["f16"] * 1e12 / (HBM_PEAK_GBS * 1e9)          # FLOP per byte where the roofs meet
-                if byts > 0 and ops / byts > ridge:
-                    roof = {"bound": "mfma", "achieved": tfs, "peak": MFMA_PEAK_TOPS["f16"], "unit": "TFLOP/s",
-                            "frac": tfs / MFMA_PEAK_TOPS["f16"], "traffic": None, "hbm_GBps_algorithmic": gbs}
-                else:
-                    roof = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                            "traffic": None, "useful_TFLOPs": tfs}
-                roof["intensity_flop_per_byte"] = ops / byts if byts else None
-            try:      # HBM bytes per launch measured with rocprofv3 --pmc in a separate run (profiles/pmc_traffic.json)
-                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-                    roof["traffic"] = json.load(f).get(dominant, None)
-            except Exception:
-                pass
-            roof.update({"kernel": dominant, "launches_per_frame": n_launch, "avg_launch_us": avg_launch_s * 1e6,
-                         "ms_per_frame": per_frame_ms})
+            roof = family_roofline(eng, dominant, timed[dominant][1] / n_roof, traffic)
+        by_kernel = {}
+        for cat, (_, ms) in sorted(warm.items(), key=lambda kv: -kv[1][1]):
+            r = family_roofline(eng, cat, ms / n_warm, traffic)
+            if r is not None:
+                by_kernel[cat] = r
         out = {
             "metric": "frames/sec/GPU int8 CenterPoint @150k pts; mAP delta vs fp32 ref" if args.workload == "centerpoint"
             else "frames/sec/GPU int8 VoxelNeXt @40k pts",
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-            "config": {"workload": wl_desc, "frames": N_FRAMES, "points": n_points, "voxels": n_voxels, "parallelism": "replicas(frames)x%d" % world,
+            "config": {"workload": wl_desc, "frames_per_rank": N_FRAMES, "frame_seeds": "4 + 8*rank + i", "points": n_points,
+                       "voxels": n_voxels, "parallelism": "replicas(frames)x%d" % world, "world_size_seen_by_rccl": world_seen,
                        "avg_boxes_per_frame": n_det / max(args.steps, 1)},
             "roofline": roof,
-            "execution": "%s, %d frames in flight" % ("hipGraph replay" if getattr(eng, "_graphs", None) else "eager launches", args.inflight),
+            "roofline_by_kernel": by_kernel,
+            "execution": "%s, %d frames in flight (throughput mode: the frames in flight share the chip)"
+                         % ("hipGraph replay" if getattr(eng, "_graphs", None) else "eager launches", args.inflight),
+            "frame_interval_ms": {"p10": pct(intervals_ms, 10), "p50": pct(intervals_ms, 50), "p90": pct(intervals_ms, 90),
+                                  "n": len(intervals_ms), "what": "host time between consecutive frame completions, rank 0, timed region"},
+            "latency_ms_single_frame": {"p10": pct(lat, 10), "p50": pct(lat, 50), "p90": pct(lat, 90), "n": len(lat),
+                                        "what": "one frame in flight: enqueue -> detection counts on the host"},
+            "value_h2d_inclusive": {"value": fps_h2d, "unit": "frames/s", "steps": n_h2d,
+                                    "what": "same pipeline, every frame's points copied from pinned host memory inside the step (rank 0)"},
             "warmup_breakdown_ms_per_frame": {k: v[1] / n_warm for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
         }
+        if world == 1 and not args.no_accuracy:
+            try:
+                out["accuracy"] = accuracy_proxy(cfg, ds, state, model, batches, N_FRAMES)
+            except Exception as e:
+                out["accuracy"] = {"failed": repr(e)}
+        else:
+            out["accuracy"] = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, ds, state)
+                out["cpu_baseline"] = cpu_baseline(cfg, ds, state, args.cpu_frames, args.cpu_warm, args.cpu_threads)
             except Exception as e:       # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
                                        "sample": "failed: %r" % (e,)}

@@ -14,17 +14,37 @@ import sys as _sys
 # multi-second stall (measured, reproducible, scratch/dbg_async5.py). The flag below selects the runtime's ordinary
 # per-node graph launch, which is unaffected and measured equally fast for this workload (359 vs 359 frames/s). The HIP
 # runtime reads it once, at its first call, so it has to be in the environment before CUDA is initialised; when that is
-# already too late, GRAPH_REPLAY_SAFE is False and the engine launches eagerly instead of replaying graphs.
+# already too late (the process holds /dev/kfd, i.e. the runtime has started — torch.cuda.is_initialized() does not
+# tell), GRAPH_REPLAY_SAFE is False and the engine launches eagerly instead of replaying graphs.
 _FLAG = "DEBUG_CLR_GRAPH_PACKET_CAPTURE"
+
+
+def _hip_runtime_started():
+    """Has the HIP/HSA runtime of this process started (and therefore read its DEBUG_CLR_* / GPU_* settings)? torch state does
+    not tell: torch.cuda.is_available() or any other HIP user starts the runtime while torch.cuda.is_initialized() stays False.
+    What does tell is the driver handle: the runtime opens /dev/kfd during its one-time initialisation, right after it has
+    read the settings. None = cannot tell (no /proc)."""
+    try:
+        for fd in _os.listdir("/proc/self/fd"):
+            try:
+                if _os.readlink("/proc/self/fd/" + fd) == "/dev/kfd":
+                    return True
+            except OSError:
+                continue
+        return False
+    except OSError:
+        return None
 
 
 def _guard_graph_replay():
     v = _os.environ.get(_FLAG)
+    started = _hip_runtime_started()
     if v is not None:
+        # a launcher-provided value counts; a value somebody put into os.environ after the runtime started does not, but that
+        # cannot be told apart here — the engine's replay self-check (tests/test_engine_gpu.py) is the backstop
         return v == "0"
-    torch = _sys.modules.get("torch")
-    if torch is not None and torch.cuda.is_initialized():
-        return False
+    if started or (started is None and "torch" in _sys.modules):
+        return False        # too late: the runtime has read (or may have read) its settings without the flag
     _os.environ[_FLAG] = "0"
     # forward_async keeps four frames in flight on eight HIP streams (index + main stream of four device plans): give each
     # stream a hardware queue of its own (the runtime's default is 4, which multiplexes two streams per queue: 507 instead of

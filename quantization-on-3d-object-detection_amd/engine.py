@@ -132,7 +132,9 @@ class Engine:
         self.max_voxels = int(vcfg.MAX_NUMBER_OF_VOXELS["test"])
         cap_opt = getattr(det, "voxel_capacity", None)
         self.cap = int(cap_opt) if cap_opt else self.max_voxels * self.batch_cap
-        self.spconv_mode = os.environ.get("AQ3D_SPCONV_MODE", "split")   # "split" (f16 hi/lo activations) | "i8" (coded gather)
+        # "coded" (int8 codes in HBM, scale folded into a per-frame fp16 hi|lo weight copy: csrc/spconv_coded.hip) |
+        # "split" (round-1 format: fp16 hi|lo activations) | "i8" (round-1 coded gather with LDS staging)
+        self.spconv_mode = os.environ.get("AQ3D_SPCONV_MODE", "coded")
         self.arena = _Arena(device)
         self.steps = []
         self.tensors = {}
@@ -224,7 +226,7 @@ class Engine:
                 wk = np.transpose(padc(codes.astype(np.float32)), (1, 0, 2))
                 rec["weight_i8"] = self._dev(wk.astype(np.int8))              # canonical int8 codes [kvol, cout, cin]
                 # staging copy of the same integers as fp16 (exact): the split-activation kernel copies it verbatim
-                split_w = q is not None and self.spconv_mode == "split"
+                split_w = q is not None and self.spconv_mode in ("split", "coded")
                 rec["weight"] = self._dev(wk.astype(np.float16)) if split_w else rec["weight_i8"]
                 rec["w_dequant"] = self._dev(padc(wdq, 1.0))
             else:   # fake-quantised fp32 weights through the fp32 weight path
@@ -247,7 +249,12 @@ class Engine:
                                 static_amax=None if aq.amax is None else self._dev(_np(aq.amax).reshape(-1)))
             use_codes = q.act_bits <= 8 and cin % 16 == 0 and rec["w_dequant"] is not None
             rec["quant"]["use_codes"] = use_codes
-            split = use_codes and self.spconv_mode == "split"
+            coded = use_codes and self.spconv_mode == "coded" and ops.spconv_coded_supported(cin, cout, kvol)
+            split = use_codes and not coded and self.spconv_mode in ("split", "coded")
+            rec["coded"] = coded
+            if coded:       # per-frame weight copy W' = code * (d_c / S) as fp16 hi | lo planes + epilogue multipliers S * t_o
+                rec["wprep"] = torch.zeros((kvol, cout, 2, cin), dtype=torch.float16, device=dev)
+                rec["out_mul"] = torch.zeros((cout,), dtype=f32, device=dev)
             rec["split"] = torch.zeros((cap, 2 * cin), dtype=torch.float16, device=dev) if split else None
             rec["codes"] = torch.zeros((cap, cin), dtype=torch.int8, device=dev) if use_codes and not split else None
             rec["fq"] = None if use_codes else torch.zeros((cap, cin), dtype=f32, device=dev)
@@ -859,6 +866,17 @@ class Engine:
             amax = q["static_amax"] if q["static_amax"] is not None else self.arena.view(x["amax"])
             if q["static_amax"] is not None and q["static_amax"].numel() == 1 and x["C"] > 1:
                 amax = q["static_amax"].expand(x["C"]).contiguous()
+            if rec.get("coded"):
+                with _Timed(self, "quantize_rows"):      # quantiser + per-frame weight copy, one launch
+                    ops.spconv_prep(x["buf"], amax, in_count, rec["weight_i8"], rec["w_dequant"], bits=q["bits"],
+                                    per_tensor=q["per_tensor"], out=(rec["codes"], rec["wprep"], rec["out_mul"]))
+                out = rec["out"]
+                with _Timed(self, "spconv_c%d" % rec["cout"]):
+                    ops.spconv_coded(rec["codes"], rec["wprep"], rec["out_mul"], nbr, lv["count"], bias=rec["bias"],
+                                     post_scale=rec["post_scale"], post_shift=rec["post_shift"],
+                                     residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
+                                     absmax_out=self.arena.view(out["amax"]), out=out["buf"])
+                return
             L = ops._lib.load()
             with _Timed(self, "quantize_rows"):
                 ops.check(L.aq3d_quantize_rows(ops._p(x["buf"]), ops._p(amax), ops._p(in_count), self.cap, x["C"], q["bits"],

@@ -48,3 +48,13 @@ def test_single_process_is_a_noop():
     assert D.frames_for_rank(5, 0, 1) == [0, 1, 2, 3, 4]
     assert D.aggregate_throughput(10, 2.0) == (10, 2.0, 5.0)
     D.barrier()
+
+
+def test_bench_gives_every_rank_its_own_frames():
+    """bench.py: rank r works on frames seeded 4 + 8 r ... 4 + 8 r + 7 — N = 1 and N = 8 do the same per-GPU work, no frame twice."""
+    sys.path.insert(0, ROOT)
+    import bench
+    seeds = [set(range(bench.rank_seed0(r), bench.rank_seed0(r) + bench.N_FRAMES)) for r in range(8)]
+    assert seeds[0] == set(range(4, 12))
+    assert all(len(s) == bench.N_FRAMES for s in seeds)
+    assert len(set().union(*seeds)) == 8 * bench.N_FRAMES

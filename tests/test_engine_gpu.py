@@ -126,3 +126,20 @@ def test_grouped_launches_and_index_stream_do_not_change_results(dev, env, monke
     else:
         assert eng.index_stream is None
     assert _same(base, other)
+
+
+def test_runtime_started_before_import_means_eager_launches():
+    """torch.cuda.is_available() starts the HIP runtime (which reads DEBUG_CLR_GRAPH_PACKET_CAPTURE once) while
+    torch.cuda.is_initialized() stays False. The package must notice (the process holds /dev/kfd) and report replay as unsafe."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('DEBUG_CLR_GRAPH_PACKET_CAPTURE', None); "
+            "import torch; ok = torch.cuda.is_available(); init = torch.cuda.is_initialized(); "
+            "import amdq3d; print(ok, init, amdq3d.GRAPH_REPLAY_SAFE)") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.split()
+    assert out[0] == "True" and out[2] == "False", out
+    code2 = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('DEBUG_CLR_GRAPH_PACKET_CAPTURE', None); "
+             "import torch; import amdq3d; print(amdq3d.GRAPH_REPLAY_SAFE, os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'))") % root
+    out2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, check=True).stdout.split()
+    assert out2 == ["True", "0"], out2        # torch imported but the runtime not started: still in time

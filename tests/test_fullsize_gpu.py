@@ -15,7 +15,7 @@ import pytest
 import torch
 
 import teacher
-from helpers import build_model, match_boxes
+from helpers import build_model, match_boxes, match_params, sane_boxes
 from oracle import centerpoint as OC
 from oracle import sparse as OS
 from oracle import voxelnext as OV
@@ -217,8 +217,17 @@ def test_s40k_voxelnext_fp32_end_to_end(dev, s40k):
     print("S40k VoxelNeXt fp32: %d boxes (oracle %d)" % (len(ps), len(s_ref)))
     assert len(s_ref) > 10
     assert abs(len(ps) - len(s_ref)) <= max(2, len(s_ref) // 50)
-    assert match_boxes(b_ref, s_ref, l_ref, pb, ps, pl) >= 0.98
-    assert match_boxes(pb, ps, pl, b_ref, s_ref, l_ref) >= 0.98
+    # every box by its parameters (1e-4); boxes of a sane size additionally at the rotated-IoU bar. The random-weight VoxelNeXt
+    # emits slivers (0.03 m x 200 m) whose IoU resolves 1e-7 parameter differences (helpers.sane_boxes).
+    sr, sp = sane_boxes(b_ref), sane_boxes(pb)
+    print("   sane-sized boxes: %d of %d; IoU-matched (all) %.3f, (sane) %.3f; parameter-matched (all) %.3f"
+          % (sr.sum(), len(sr), match_boxes(b_ref, s_ref, l_ref, pb, ps, pl), match_boxes(b_ref[sr], s_ref[sr], l_ref[sr], pb, ps, pl),
+             match_params(b_ref, s_ref, l_ref, pb, ps, pl)))
+    assert match_params(b_ref, s_ref, l_ref, pb, ps, pl) >= 0.98
+    assert match_params(pb, ps, pl, b_ref, s_ref, l_ref) >= 0.98
+    assert sr.sum() > 10
+    assert match_boxes(b_ref[sr], s_ref[sr], l_ref[sr], pb, ps, pl) >= 0.98
+    assert match_boxes(pb[sp], ps[sp], pl[sp], b_ref, s_ref, l_ref) >= 0.98
     res = teacher.sparse_layers(eng, maps, _vn_rows(trace))
     teacher.report("S40k VoxelNeXt fp32, teacher-forced layers", res)
     _assert_layers(res, 1e-5)
