@@ -125,6 +125,13 @@ int aq3d_conv_outputs(const int32_t *coords_in, const int32_t *count_in, int32_t
                       int64_t *out_keys, int32_t *out_vals, int32_t out_table_size,
                       void *workspace, size_t workspace_bytes, void *stream);
 
+/* Tile order of a gather table (no reference counterpart: spconv's implicit-GEMM "mask argsort" plays this role inside the
+ * library the reference calls at pcdet/models/backbones_3d/spconv_backbone.py:12-17): rows of nbr i32 [*count, kvol] are
+ * grouped by their occupancy pattern (sorted per chunk of 16 384 rows). perm_out i32 [cap]: position i of the tile order is
+ * output row perm_out[i]; nbr_sorted_out i32 [cap, kvol]: row i = nbr[perm_out[i]]. Consumed by aq3d_spconv_coded(perm). */
+int aq3d_tile_order(const int32_t *nbr, const int32_t *count, int32_t cap, int32_t kvol, int32_t *perm_out,
+                    int32_t *nbr_sorted_out, void *stream);
+
 /* ---------------------------------------------------------------- sparse conv ----------------- */
 
 /* Per-column abs-max of x f32 [*count, C] → amax f32 [C] (amax must be zeroed by the caller). */

@@ -206,14 +206,18 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
             const int i1 = j1 < KVOL ? nb[j1 < KVOL ? j1 : KVOL - 1] : -1;
             const int idx = (g >> 1) ? i1 : i0;
             const unsigned off = idx >= 0 ? (unsigned)(idx * CIN + (g & 1) * 8) : CD_OOB;
-            const i32x2v cv = __builtin_amdgcn_raw_buffer_load_b64(rsrc_f, off, 0, 0);
-            const f16x8 fa = cd_cvt8(cv.x, cv.y);
+            const i32x2v cv = __builtin_amdgcn_raw_buffer_load_b64(rsrc_f, off, 0, 0);   // no neighbour: out of range, no traffic
+            // none of the wave's 16 rows has a neighbour at these two offsets (the common case once the rows are in tile
+            // order): skip the conversion, the LDS reads and the MFMAs — adding exact zeros changes nothing
+            if (__builtin_amdgcn_ballot_w64(idx >= 0) != 0ull) {
+                const f16x8 fa = cd_cvt8(cv.x, cv.y);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const f16x8 fh = *reinterpret_cast<const f16x8 *>(Bh + bofs + nt * 16 * LD + q * 32);
-                const f16x8 fl = *reinterpret_cast<const f16x8 *>(Bl + bofs + nt * 16 * LD + q * 32);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fh, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fl, acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f16x8 fh = *reinterpret_cast<const f16x8 *>(Bh + bofs + nt * 16 * LD + q * 32);
+                    const f16x8 fl = *reinterpret_cast<const f16x8 *>(Bl + bofs + nt * 16 * LD + q * 32);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fh, acc[nt], 0, 0, 0);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fl, acc[nt], 0, 0, 0);
+                }
             }
         }
         // epilogue (D layout: col = lane&15 -> out channel, row = 4g + reg)

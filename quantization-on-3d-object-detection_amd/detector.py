@@ -133,6 +133,17 @@ class Detector3DTemplate(nn.Module):
         assert self.model_cfg.get("ROI_HEAD", None) is None, "ROI_HEAD is outside the CenterPoint hot path"
         return None, model_info_dict
 
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """The compiled device plans bake folded-BN and quantised weights in: any weight load drops them (rebuilt on the next
+        forward). In-place parameter edits are not tracked — call invalidate_engine() after them."""
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.invalidate_engine()
+        return out
+
+    def invalidate_engine(self):
+        self._engine = None
+        self._extra_engines = []
+
     # ------------------------------------------------------------------ checkpoints (detector3d_template.py:330-384)
     def _load_state_dict(self, model_state_disk, *, strict=True):
         state_dict = self.state_dict()
@@ -156,7 +167,7 @@ class Detector3DTemplate(nn.Module):
         else:
             state_dict.update(update_model_state)
             self.load_state_dict(state_dict)
-        self._engine = None
+        self.invalidate_engine()
         return state_dict, update_model_state
 
     def load_params_from_file(self, filename, logger, to_cpu=False, pre_trained_path=None):
@@ -229,13 +240,24 @@ class PendingFrame:
 
     def __init__(self, det, eng, slot, B, batch_dict):
         self.det, self.eng, self.slot, self.B, self.batch_dict = det, eng, slot, B, batch_dict
+        self.generation = eng.slot_generation[slot]      # the plan's result slot is reused NSLOT frames later
+        self._counts = None
+
+    def _check_live(self):
+        if self.eng.slot_generation[self.slot] != self.generation:
+            raise RuntimeError("this PendingFrame's result slot has been reused by a later frame of the same device plan: read "
+                               "counts()/result() before enqueueing Engine.NSLOT further frames on that plan")
 
     def counts(self):
         """Detections per (sample, head) — one event wait + a pinned-host read, no tensor slicing."""
-        return self.eng.counts(self.B, self.slot)
+        if self._counts is None:
+            self._check_live()
+            self._counts = self.eng.counts(self.B, self.slot)
+        return self._counts
 
     def result(self):
         """→ (pred_dicts, recall_dict), exactly what Detector.forward returns."""
+        self._check_live()
         self.batch_dict["final_box_dicts"] = self.eng.collect(self.B, self.slot)
         return self.det.post_processing(self.batch_dict)
 
@@ -264,7 +286,9 @@ class CenterPoint(Detector3DTemplate):
         return self.post_processing(batch_dict)
 
     def forward_async(self, batch_dict):
-        """Enqueue a frame without reading anything back → PendingFrame. Up to Engine.NSLOT frames may be in flight: enqueue
+        """Enqueue a frame without reading anything back → PendingFrame. One frame per device plan is in flight (the call blocks
+        until the plan's previous frame has finished); a plan keeps Engine.NSLOT result slots, so a PendingFrame stays readable
+        until NSLOT later frames have been enqueued on ITS plan (after that counts()/result() raise). Enqueue
         frame N+1, then call .result() of frame N (serving loops hide the host-side launch work behind the GPU this way)."""
         if self.training:
             raise NotImplementedError("inference-only build: call model.eval() (training is outside the hot path)")

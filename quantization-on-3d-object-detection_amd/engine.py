@@ -135,6 +135,8 @@ class Engine:
         # "coded" (int8 codes in HBM, scale folded into a per-frame fp16 hi|lo weight copy: csrc/spconv_coded.hip) |
         # "split" (round-1 format: fp16 hi|lo activations) | "i8" (round-1 coded gather with LDS staging)
         self.spconv_mode = os.environ.get("AQ3D_SPCONV_MODE", "coded")
+        # rows of the gather tables grouped by neighbour pattern so that 128-row tiles skip kernel offsets (csrc/tile_order.hip)
+        self.tile_order = os.environ.get("AQ3D_TILE_ORDER", "1") != "0"
         self.arena = _Arena(device)
         self.steps = []
         self.tensors = {}
@@ -156,6 +158,7 @@ class Engine:
         self._graph_now = self._warm_now = False
         self._index_batch = self._static_batch = None
         self.slot = 0
+        self.slot_generation = [0] * self.NSLOT
         self.use_graph = device.type == "cuda" and os.environ.get("AQ3D_GRAPH", "1") != "0"
         if self.use_graph and not _graph_replay_safe():
             import warnings
@@ -186,7 +189,7 @@ class Engine:
         dev, cap = self.device, self.cap
         lv = dict(shape=list(shape), coords=torch.zeros((cap, 4), dtype=i32, device=dev),
                   count=torch.zeros((1,), dtype=i32, device=dev), table=ops.HashTable(cap, dev),
-                  nbr=torch.full((cap, kvol), -1, dtype=i32, device=dev), subm_ksize=(3, 3, 3))
+                  nbr=torch.full((cap, kvol), -1, dtype=i32, device=dev), subm_ksize=(3, 3, 3), tiled=None)
         self.levels.append(lv)
         return lv
 
@@ -252,7 +255,8 @@ class Engine:
             coded = use_codes and self.spconv_mode == "coded" and ops.spconv_coded_supported(cin, cout, kvol)
             split = use_codes and not coded and self.spconv_mode in ("split", "coded")
             rec["coded"] = coded
-            if coded:       # per-frame weight copy W' = code * (d_c / S) as fp16 hi | lo planes + epilogue multipliers S * t_o
+            if coded:
+                self._request_tile_order(nbr)       # per-frame weight copy W' = code * (d_c / S) as fp16 hi | lo planes + epilogue multipliers S * t_o
                 rec["wprep"] = torch.zeros((kvol, cout, 2, cin), dtype=torch.float16, device=dev)
                 rec["out_mul"] = torch.zeros((cout,), dtype=f32, device=dev)
             rec["split"] = torch.zeros((cap, 2 * cin), dtype=torch.float16, device=dev) if split else None
@@ -845,6 +849,32 @@ class Engine:
             return self.levels[ref[1]]["down"]["nbr"]
         return self.levels[ref]["nbr"]
 
+    def _tile_of(self, ref, level=None):
+        """(gather table in tile order, perm) of a table reference when its rows have been grouped by neighbour pattern
+        (aq3d_tile_order, index phase), else (table, None)."""
+        holder = None
+        if isinstance(ref, tuple):
+            if ref[0] == "down":
+                holder = self.levels[ref[1]]["down"]
+        else:
+            holder = self.levels[ref]
+        t = holder.get("tiled") if holder is not None else None
+        if t is None:
+            return self._nbr_of(ref, level), None
+        return t["nbr"], t["perm"]
+
+    def _request_tile_order(self, ref):
+        """Compile time: the coded convs that read this table want it in tile order (buffers + an index-phase step)."""
+        if not self.tile_order:
+            return
+        holder = self.levels[ref[1]]["down"] if isinstance(ref, tuple) else self.levels[ref]
+        if isinstance(ref, tuple) and ref[0] != "down":
+            return
+        if holder.get("tiled") is None:
+            nbr = holder["nbr"]
+            holder["tiled"] = dict(nbr=torch.full(tuple(nbr.shape), -1, dtype=i32, device=self.device),
+                                   perm=torch.zeros((self.cap,), dtype=i32, device=self.device))
+
     def _spconv_ws(self):
         """Scratch for the split-tile mode of the wide kernel (AQ3D_WIDE_SPLIT=1; measured SLOWER than whole tiles — the doubled
         prologue, the 64 KB accumulator hand-over and co-residency cost more than the idle CUs — so it is off by default)."""
@@ -871,8 +901,9 @@ class Engine:
                     ops.spconv_prep(x["buf"], amax, in_count, rec["weight_i8"], rec["w_dequant"], bits=q["bits"],
                                     per_tensor=q["per_tensor"], out=(rec["codes"], rec["wprep"], rec["out_mul"]))
                 out = rec["out"]
+                nbr_t, perm = self._tile_of(rec["nbr"], rec["level"])
                 with _Timed(self, "spconv_c%d" % rec["cout"]):
-                    ops.spconv_coded(rec["codes"], rec["wprep"], rec["out_mul"], nbr, lv["count"], bias=rec["bias"],
+                    ops.spconv_coded(rec["codes"], rec["wprep"], rec["out_mul"], nbr_t, lv["count"], perm=perm, bias=rec["bias"],
                                      post_scale=rec["post_scale"], post_shift=rec["post_shift"],
                                      residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
                                      absmax_out=self.arena.view(out["amax"]), out=out["buf"])
@@ -992,6 +1023,7 @@ class Engine:
         if B > self.batch_cap:
             raise ValueError("batch_size %d exceeds the engine's max_batch_size %d" % (B, self.batch_cap))
         self.slot = (self.slot + 1) % self.NSLOT
+        self.slot_generation[self.slot] += 1        # PendingFrame handles of the slot's previous frame are stale from here on
         self._graph_now = self._graph_ok(batch_dict, B)
         self._warm_now = self._graph_now and self._warm < 1     # first frame: eager, settles workspaces / kernel attributes
         if self._warm_now:
@@ -1164,9 +1196,14 @@ class Engine:
                 if "down" not in lv:   # level 0: table from the voxel coords; deeper levels get it from conv_outputs
                     ops.hash_build(lv["coords"], lv["count"], lv["shape"], lv["table"])
                 ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], lv["subm_ksize"], lv["table"], out=lv["nbr"])
+                if lv.get("tiled") is not None:
+                    ops.tile_order(lv["nbr"], lv["count"], out=(lv["tiled"]["perm"], lv["tiled"]["nbr"]))
         elif kind == "index_down":
             with _Timed(self, "rulebook"):
                 self._index_down(arg)
+                d = self.levels[arg]["down"]
+                if d.get("tiled") is not None:
+                    ops.tile_order(d["nbr"], self.levels[arg]["count"], out=(d["tiled"]["perm"], d["tiled"]["nbr"]))
         elif kind == "index_head":
             lv = self.levels[arg]
             with _Timed(self, "rulebook"):

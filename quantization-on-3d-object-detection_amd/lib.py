@@ -68,6 +68,7 @@ SIGNATURES = {
     "aq3d_conv_outputs_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "aq3d_conv_outputs": (c_int32, [P, P, c_int32, I3, I3, I3, I3, P, P, c_int32, P, P, c_int32, P, P, P, c_int32,
                                     P, c_size_t, P]),
+    "aq3d_tile_order": (c_int32, [P, P, c_int32, c_int32, P, P, P]),
     "aq3d_absmax_cols": (c_int32, [P, P, c_int32, c_int32, P, P]),
     "aq3d_quantize_rows": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, P, P, P, P, P]),
     "aq3d_spconv": (c_int32, [P, c_int32, P, P, c_int32, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32,

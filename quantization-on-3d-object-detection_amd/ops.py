@@ -118,6 +118,19 @@ def subm_neighbors(coords, count, shape, ksize, table, out=None):
     return nbr
 
 
+def tile_order(nbr, count, out=None):
+    """Rows of a gather table grouped by neighbour pattern → (perm i32 [cap], nbr_sorted i32 [cap, kvol]); see aq3d_tile_order."""
+    L = _lib.load()
+    cap, kvol = nbr.shape
+    if out is None:
+        perm = torch.zeros((cap,), dtype=i32, device=nbr.device)
+        nbr_t = torch.full((cap, kvol), -1, dtype=i32, device=nbr.device)
+    else:
+        perm, nbr_t = out
+    check(L.aq3d_tile_order(_p(nbr), _p(count), cap, kvol, _p(perm), _p(nbr_t), _stream()), "aq3d_tile_order")
+    return perm, nbr_t
+
+
 def conv_out_shape(shape, ksize, stride, pad):
     return [(shape[i] + 2 * pad[i] - ksize[i]) // stride[i] + 1 for i in range(3)]
 

@@ -33,7 +33,7 @@ def timeit(fn):
     return e0.elapsed_time(e1) * 1e3 / ITERS
 
 
-tot_old = tot_new = 0.0
+tot_old = tot_new = tot_tiled = 0.0
 for rec in eng.sparse_convs:
     q = rec["quant"]
     if q is None or not q["on"] or rec.get("weight_i8") is None:
@@ -71,13 +71,24 @@ for rec in eng.sparse_convs:
         ops.spconv_coded(bufs[0], bufs[1], bufs[2], nbr, cnt_out, bias=rec["bias"], post_scale=rec["post_scale"],
                          post_shift=rec["post_shift"], residual=res, relu=rec["relu"], out=out_b)
 
-    q_old(); c_old(); q_new(); c_new()
+    perm, nbr_t = ops.tile_order(nbr, cnt_out)
+    out_c = torch.zeros_like(rec["out"]["buf"])
+
+    def c_tiled():
+        ops.spconv_coded(bufs[0], bufs[1], bufs[2], nbr_t, cnt_out, perm=perm, bias=rec["bias"], post_scale=rec["post_scale"],
+                         post_shift=rec["post_shift"], residual=res, relu=rec["relu"], out=out_c)
+
+    def t_order():
+        ops.tile_order(nbr, cnt_out, out=(perm, nbr_t))
+
+    q_old(); c_old(); q_new(); c_new(); c_tiled()
     torch.cuda.synchronize()
+    assert torch.equal(out_b[:int(cnt_out.item())], out_c[:int(cnt_out.item())]), "tile order changed values"
     m = int(cnt_out.item())
     d = (out_a[:m] - out_b[:m]).abs().max().item() / max(1.0, out_a[:m].abs().max().item())
-    t = [timeit(f) for f in (q_old, c_old, q_new, c_new)]
+    t = [timeit(f) for f in (q_old, c_old, q_new, c_new, c_tiled, t_order)]
     pairs = int((nbr[:m] >= 0).sum().item())
-    tot_old += t[0] + t[1]; tot_new += t[2] + t[3]
-    print("%-30s %3d->%3d k%-2d rows %6d pairs/row %4.1f | old quant %5.1f conv %6.1f | new prep %5.1f conv %6.1f us | rel diff %.1e"
-          % (rec["path"][12:], cin, cout, kvol, m, pairs / max(m, 1), t[0], t[1], t[2], t[3], d), flush=True)
-print("sum over quantised layers: old %.1f us, new %.1f us" % (tot_old, tot_new))
+    tot_old += t[0] + t[1]; tot_new += t[2] + t[3]; tot_tiled += t[2] + t[4]
+    print("%-30s %3d->%3d k%-2d rows %6d pairs/row %4.1f | old quant %5.1f conv %6.1f | new prep %5.1f conv %6.1f tiled %6.1f (sort %5.1f) us | rel diff %.1e"
+          % (rec["path"][12:], cin, cout, kvol, m, pairs / max(m, 1), t[0], t[1], t[2], t[3], t[4], t[5], d), flush=True)
+print("sum over quantised layers: old %.1f us, new %.1f us, new in tile order %.1f us" % (tot_old, tot_new, tot_tiled))

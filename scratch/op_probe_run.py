@@ -21,31 +21,40 @@ if wl == "voxelnext":
     model.async_streams = 2
 diag = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag", "libaq3d_diag.so"))
 P = ctypes.c_void_p
-diag.aq3d_diag_op_probe.argtypes = [P, ctypes.c_int32, ctypes.c_int32, P, P]
-diag.aq3d_diag_op_probe.restype = ctypes.c_int32
+NAMES2 = ["rotated_overlap (production function)", "seg_intersection x16 + corner tests", "corner tests x8 only",
+          "seg_intersection x16 only", "branch-free seg_intersection x16", "accept tests of seg_intersection only (no division)",
+          "the divisions only (unconditional)", "ONE seg_intersection"]
 BLOCKS = int(os.environ.get("BLOCKS", "256"))
-ref = torch.zeros((len(NAMES) * BLOCKS * 64,), dtype=torch.float32, device=dev)
-counters = torch.zeros((32,), dtype=torch.int32, device=dev)
+PROBES = []
+for sym, names in (("aq3d_diag_op_probe", NAMES), ("aq3d_diag_op_probe2_pk", NAMES2), ("aq3d_diag_op_probe2_nopk", NAMES2)):
+    fn = getattr(diag, sym)
+    fn.argtypes = [P, ctypes.c_int32, ctypes.c_int32, P, P]
+    fn.restype = ctypes.c_int32
+    PROBES.append(dict(sym=sym, fn=fn, names=names, ref=torch.zeros((16 * BLOCKS * 64,), dtype=torch.float32, device=dev),
+                       counters=torch.zeros((32,), dtype=torch.int32, device=dev)))
 
 
 def probe(have_ref):
-    assert diag.aq3d_diag_op_probe(ops._p(ref), BLOCKS, int(have_ref), ops._p(counters), ops._stream()) == 0
+    for p in PROBES:
+        assert p["fn"](ops._p(p["ref"]), BLOCKS, int(have_ref), ops._p(p["counters"]), ops._stream()) == 0
 
 
 def show(title):
     torch.cuda.synchronize()
-    c = counters.tolist()
-    print("%s: %d launches, %d lanes per class" % (title, c[31], c[30]))
-    for i, n in enumerate(NAMES):
-        print("   %-48s in-launch mismatches %8d   vs quiet reference %8d" % (n, c[2 * i], c[2 * i + 1]))
+    for p in PROBES:
+        c = p["counters"].tolist()
+        print("%s — %s: %d launches, %d lanes per class" % (title, p["sym"], c[31], c[30]))
+        for i, n in enumerate(p["names"]):
+            print("   %-52s in-launch mismatches %8d   vs quiet reference %8d" % (n, c[2 * i], c[2 * i + 1]))
+        p["counters"].zero_()
     sys.stdout.flush()
-    counters.zero_()
     torch.cuda.synchronize()
 
 
 probe(0)
 torch.cuda.synchronize()
-counters.zero_()
+for p in PROBES:
+    p["counters"].zero_()
 for _ in range(300):
     probe(1)
 show("alone (300 launches, nothing else on the chip)")
@@ -67,7 +76,8 @@ with torch.no_grad():
     for i in range(16):
         model.forward_async(dict(batches[i % NF])).counts()
     torch.cuda.synchronize()
-    counters.zero_()
+    for p in PROBES:
+        p["counters"].zero_()
     engs = [model._engine] + model._extra_engines
     steps = int(os.environ.get("STEPS", "3000"))
     pend = collections.deque()

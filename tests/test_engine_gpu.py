@@ -143,3 +143,28 @@ def test_runtime_started_before_import_means_eager_launches():
              "import torch; import amdq3d; print(amdq3d.GRAPH_REPLAY_SAFE, os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'))") % root
     out2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, check=True).stdout.split()
     assert out2 == ["True", "0"], out2        # torch imported but the runtime not started: still in time
+
+
+def test_stale_pending_frame_raises_and_weight_load_rebuilds_the_plan(dev, monkeypatch):
+    """(i) a PendingFrame whose result slot was handed to a later frame must not silently return that frame's
+    detections; (ii) nn.Module.load_state_dict after the first forward must not keep serving the old compiled weights."""
+    monkeypatch.setenv("AQ3D_ASYNC_ENGINES", "1")
+    ds, model = _model(quantized=False)
+    from amdq3d.engine import Engine
+    with torch.no_grad():
+        first = model.forward_async(_batch(ds, 0, dev))
+        keep = [model.forward_async(_batch(ds, 1 + (i % 2), dev)) for i in range(Engine.NSLOT)]
+        with pytest.raises(RuntimeError, match="reused"):
+            first.result()
+        ok = keep[-1].result()
+        ref = _np(model(_batch(ds, 0, dev))[0][0])
+    assert len(ok[0]) == 1
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+    for k in state:
+        if k.endswith("hm.1.bias"):
+            state[k] = state[k] - 3.0                    # far fewer pixels pass the score threshold
+    model.load_state_dict(state)
+    assert model._engine is None
+    with torch.no_grad():
+        got = _np(model(_batch(ds, 0, dev))[0][0])
+    assert len(got[1]) < len(ref[1])
