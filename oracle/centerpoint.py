@@ -30,8 +30,29 @@ def _bn_np(state, prefix):
 
 
 class Recipe:
-    def __init__(self, w_bits=8, act_bits=8, sq=True, alpha=0.5):
+    """static: {module path: {'act': amax [C] or scalar (QConvNd) | 'x': float, 'w': [O] (SQConv2d / quant conv)}} — calibrated
+    amax of quant_centerpoint.py:127-129 (collect_stats + compute_amax), the quantizers then clip instead of following the
+    frame. collect: a dict that a CALIBRATION forward fills with the running element-wise max of what each quantizer sees
+    (MaxCalibrator); in that forward nothing is quantised (quantize.py:178-181: enable_calib + disable_quant)."""
+
+    def __init__(self, w_bits=8, act_bits=8, sq=True, alpha=0.5, static=None, collect=None):
         self.w_bits, self.act_bits, self.sq, self.alpha = w_bits, act_bits, sq, alpha
+        self.static, self.collect = static, collect
+
+
+def _running_max(store, path, key, value):
+    value = np.asarray(value, dtype=np.float32)
+    d = store.setdefault(path, {})
+    d[key] = value.copy() if key not in d else np.maximum(d[key], value)
+
+
+def calibrate(state, cfg, frames, recipe):
+    """collect_stats (quant/quantize.py:175-195) over `frames` (list of point arrays) → the `static` dict for Recipe."""
+    store = {}
+    cal = Recipe(recipe.w_bits, recipe.act_bits, recipe.sq, recipe.alpha, collect=store)
+    for pts in frames:
+        run(state, cfg, pts, cal)
+    return store
 
 
 def sparse_backbone(state, feats, coords, sparse_shape, recipe, trace=None):
@@ -43,9 +64,16 @@ def sparse_backbone(state, feats, coords, sparse_shape, recipe, trace=None):
         b = state.get(P + path + ".bias", None)
         b = None if b is None else b.float().numpy()
         quantized = recipe is not None and not (recipe.sq and (P + path) in BACKBONE_NO_LIST)
-        if quantized:
-            w, _, _ = S.qconv_weight(w, recipe.w_bits)
-            x, _ = S.qconv_act(x, recipe.act_bits, cw=recipe.sq)
+        if quantized and recipe.collect is not None:
+            from . import quantizer as Q
+            _running_max(recipe.collect, P + path, "act", Q.reduce_amax(x, axis=1 if recipe.sq else None).reshape(-1))
+        elif quantized:
+            w, _, _ = S.qconv_weight(w, recipe.w_bits)      # constant weights: calibrated amax == dynamic amax
+            amax = None
+            if recipe.static is not None:
+                amax = np.asarray(recipe.static[P + path]["act"], dtype=np.float32)
+                amax = amax.reshape(1, -1) if recipe.sq else np.float32(amax.reshape(-1)[0])
+            x, _ = S.qconv_act(x, recipe.act_bits, cw=recipe.sq, amax=amax)
         y = S.gather_conv(x, w, nbr, b)
         y = S.batchnorm(y, _bn_np(state, P + bn_prefix), 1e-3)
         if residual is not None:
@@ -83,8 +111,16 @@ def _conv2d(state, path, x, stride, padding, recipe, quantized):
     w = state[path + ".weight"].float()
     b = state.get(path + ".bias", None)
     b = None if b is None else b.float()
+    if quantized and recipe.collect is not None:
+        y, st = DN.sq_conv2d(x, w, b, stride, padding, recipe.alpha if recipe.sq else None, recipe.w_bits, recipe.act_bits,
+                             return_stats=True, quantize=False)
+        _running_max(recipe.collect, path, "x", st["amax_x"])
+        _running_max(recipe.collect, path, "w", st["amax_w"])
+        return y
     if quantized:
-        return DN.sq_conv2d(x, w, b, stride, padding, recipe.alpha if recipe.sq else None, recipe.w_bits, recipe.act_bits)
+        st = recipe.static[path] if recipe.static is not None else {}
+        return DN.sq_conv2d(x, w, b, stride, padding, recipe.alpha if recipe.sq else None, recipe.w_bits, recipe.act_bits,
+                            amax_x=st.get("x"), amax_w=st.get("w"))
     return F.conv2d(x, w, b, stride, padding)
 
 

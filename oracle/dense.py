@@ -35,8 +35,12 @@ def smooth_scale(act_scale, w_scale, alpha):
     return torch.from_numpy(s)
 
 
-def sq_conv2d(x, weight, bias, stride, padding, alpha, w_bits=8, a_bits=8, amax_x=None, amax_w=None, return_stats=False):
-    """x [B,C,H,W], weight [O,I,k,k]. alpha=None → no smoothing (plain per-tensor act / per-oc weight fake quant)."""
+def sq_conv2d(x, weight, bias, stride, padding, alpha, w_bits=8, a_bits=8, amax_x=None, amax_w=None, return_stats=False,
+              quantize=True):
+    """x [B,C,H,W], weight [O,I,k,k]. alpha=None → no smoothing (plain per-tensor act / per-oc weight fake quant).
+    amax_x / amax_w: calibrated amax (static PTQ: values beyond them clip at -2^(b-1) / 2^(b-1)-1). quantize=False is the
+    calibration forward of quant/quantize.py:175-195 (quantizers disabled, calibrators enabled): the smoothed operands go
+    through unquantised and the amax the two quantizers see is returned in the stats."""
     O, I, k, _ = weight.shape
     ick = I * k * k
     w = weight.reshape(O, ick)
@@ -51,8 +55,8 @@ def sq_conv2d(x, weight, bias, stride, padding, alpha, w_bits=8, a_bits=8, amax_
         cols = cols / scale
     aw = Q.reduce_amax(w.numpy(), axis=0) if amax_w is None else np.asarray(amax_w, np.float32).reshape(O, 1)
     ax = Q.reduce_amax(cols.numpy(), axis=None) if amax_x is None else np.float32(amax_x)
-    wq = _fq(w, aw, w_bits)
-    xq = _fq(cols, ax, a_bits)
+    wq = _fq(w, aw, w_bits) if quantize else w
+    xq = _fq(cols, ax, a_bits) if quantize else cols
     y = xq @ wq.T
     y = y.view(bs, -1, O).permute(0, 2, 1)
     h_out = (h_in + 2 * padding - (k - 1) - 1) // stride + 1

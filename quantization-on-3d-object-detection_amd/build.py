@@ -19,8 +19,14 @@ OBJ_DIR = os.path.join(CSRC, "build")
 HIPCC = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 ARCH = "gfx950"
 # No -ffast-math: voxel indices and integer codes must be bit-exact (IEEE divide, round-half-even).
+# No packed-fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 / v_pk_mov_b32 ...): on this stack (gfx950, ROCm 7.2) the
+# forms the compiler generates for the rotated-overlap geometry are not a pure function of their inputs while kernels of other
+# HIP streams share the CU — the cause of the NMS masks that differed between identical frames in round 1. Measured with
+# scratch/diag/op_probe2.hip, the same source built twice: 100 k - 440 k mismatching lanes of 2.9e8 with packed ops, 0 without
+# (8 formulations, profiles/r02_nms/rootcause_evidence.txt). They buy nothing here either (round 1: ~4x the issue cost of a plain op).
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 CFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fno-fast-math", "-ffp-contract=off",
-          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"]
+          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value"] + NO_PACKED_FP32
 
 
 def _sources():
@@ -47,8 +53,9 @@ def _compile(src):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
-    if r.stderr.strip():
-        sys.stderr.write(r.stderr)
+    err = "\n".join(l for l in r.stderr.splitlines() if "is not a recognized feature for this target" not in l)   # host pass of the device-only feature flag
+    if err.strip():
+        sys.stderr.write(err + "\n")
     return obj
 
 

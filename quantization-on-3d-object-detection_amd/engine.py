@@ -135,8 +135,11 @@ class Engine:
         # "coded" (int8 codes in HBM, scale folded into a per-frame fp16 hi|lo weight copy: csrc/spconv_coded.hip) |
         # "split" (round-1 format: fp16 hi|lo activations) | "i8" (round-1 coded gather with LDS staging)
         self.spconv_mode = os.environ.get("AQ3D_SPCONV_MODE", "coded")
-        # rows of the gather tables grouped by neighbour pattern so that 128-row tiles skip kernel offsets (csrc/tile_order.hip)
-        self.tile_order = os.environ.get("AQ3D_TILE_ORDER", "1") != "0"
+        # rows of the gather tables grouped by neighbour pattern so that 128-row tiles skip kernel offsets (csrc/tile_order.hip).
+        # Measured on W150k (profiles/r02_*): the 128-channel SubM layers go 110 -> 96 us, the 64->128 strided conv 67 -> 49 us,
+        # the narrower levels do not move (they are not bound by the matrix pipe), and the LDS sort costs 360 us per table on
+        # the index stream — a net loss at this frame size (396 vs 575 frames/s with all nine tables sorted), so it is opt-in.
+        self.tile_order = os.environ.get("AQ3D_TILE_ORDER", "0") != "0"
         self.arena = _Arena(device)
         self.steps = []
         self.tensors = {}

@@ -10,7 +10,7 @@ NOPK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 def build():
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     objs = []
-    for src, extra, tag in (("nms_diag.hip", [], ""), ("op_probe.hip", [], ""), ("op_probe2.hip", ["-DPROBE_TAG=pk"], "_pk"),
+    for src, extra, tag in (("nms_diag.hip", NOPK, ""), ("op_probe.hip", [], ""), ("op_probe2.hip", ["-DPROBE_TAG=pk"], "_pk"),
                             ("op_probe2.hip", ["-DPROBE_TAG=nopk"] + NOPK, "_nopk")):
         obj = os.path.join(HERE, "build", src + tag + ".o")
         r = subprocess.run([HIPCC] + FLAGS + extra + ["-c", os.path.join(HERE, src), "-o", obj], capture_output=True, text=True)

@@ -168,3 +168,40 @@ def test_batch_of_two_equals_single(dev):
         assert torch.equal(p1["pred_boxes"], pred2[i]["pred_boxes"])
         assert torch.equal(p1["pred_scores"], pred2[i]["pred_scores"])
         assert torch.equal(p1["pred_labels"], pred2[i]["pred_labels"])
+
+
+def test_prevoxelized_batch_dict_and_mean_vfe(dev):
+    """The pcdet input contract: `voxels [M,P,C]`, `voxel_num_points [M]`, `voxel_coords [M,4]` as float tensors
+    from the reference's CPU voxelizer (data_processor.py:133-180 + load_data_to_gpu, pcdet/models/__init__.py:23-36), consumed
+    through aq3d_mean_vfe (vfe/mean_vfe.py:14-31) when model.voxelize_on_device is False: aq3d_mean_vfe is bit-exact against the
+    oracle and the detections equal those of the raw-points path (on-device voxelizer) bit for bit."""
+    from amdq3d import ops
+    from amdq3d.datasets import load_data_to_gpu
+    from oracle import voxel as OVX
+    cfg = small_cfg("waymo")
+    ds, model = build_model(cfg, n_points=9000, n_voxels=2500)
+    model.cuda()
+    ref, _ = _run_gpu(model, ds, 0, dev)
+    pts = ds[0]["points"]
+    pr = [float(v) for v in cfg.DATA_CONFIG.POINT_CLOUD_RANGE]
+    vox = {c.NAME: c for c in cfg.DATA_CONFIG.DATA_PROCESSOR}["transform_points_to_voxels"]
+    voxels, coords, num = OVX.hard_voxelize(pts, pr, [float(v) for v in vox.VOXEL_SIZE], vox.MAX_POINTS_PER_VOXEL,
+                                            vox.MAX_NUMBER_OF_VOXELS["test"])
+    got = ops.mean_vfe(torch.from_numpy(voxels).to(dev), torch.from_numpy(num).to(dev)).cpu().numpy()
+    np.testing.assert_array_equal(got, OVX.mean_vfe(voxels, num))
+    batch = {"voxels": voxels, "voxel_num_points": num,
+             "voxel_coords": np.concatenate([np.zeros((len(coords), 1), np.int32), coords], 1), "batch_size": 1,
+             "frame_id": np.array(["f0"])}
+    load_data_to_gpu(batch, dev)
+    assert batch["voxel_coords"].dtype == torch.float32            # the reference casts everything to float (and back in the backbone)
+    model.voxelize_on_device = False
+    with torch.no_grad():
+        pred, _ = model(batch)
+    for k in ("pred_boxes", "pred_scores", "pred_labels"):
+        assert torch.equal(pred[0][k], ref[k]), k
+    # more voxels than the plan holds: a clear error, not silent truncation
+    model.voxel_capacity = 1000
+    model.invalidate_engine()
+    with pytest.raises(ValueError, match="capacity"):
+        with torch.no_grad():
+            model(batch)

@@ -257,8 +257,9 @@ def test_tile_order(dev, m, kvol):
     rows copied accordingly — and far fewer (128-row tile, offset) units with any neighbour than in voxelizer order."""
     from amdq3d import ops
     rng = np.random.default_rng(m + kvol)
-    dens = rng.uniform(0.02, 0.6, kvol)
-    live = rng.random((m, kvol)) < dens[None, :]
+    # LiDAR-like: a few dozen recurring neighbour patterns (surfaces) plus noise, rows in shuffled order
+    protos = rng.random((48, kvol)) < rng.uniform(0.05, 0.6, (48, 1))
+    live = protos[rng.integers(0, 48, m)] ^ (rng.random((m, kvol)) < 0.01)
     live[:, kvol // 2] = True
     nbr_h = np.where(live, rng.integers(0, m, (m, kvol)), -1).astype(np.int32)
     cap = m + 77

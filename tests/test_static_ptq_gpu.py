@@ -50,3 +50,64 @@ def test_static_calibration_collects_running_max_and_runs(dev):
     rel = float((bev_static - bev_dyn).pow(2).mean().sqrt() / bev_dyn.pow(2).mean().sqrt())
     assert rel < 0.2
     assert pred_s[0]["pred_boxes"].shape[1] == 7 and pred_s[0]["pred_scores"].numel() > 0
+
+
+def _set_static(model, static, Qz):
+    """Calibrated amax of the oracle → the descriptors' quantizers (what compute_amax would have loaded)."""
+    mods = dict(model.named_modules())
+    for path, d in static.items():
+        m = mods[path]
+        if "act" in d:
+            m.act_quant._amax = torch.from_numpy(np.asarray(d["act"], np.float32).reshape(-1).copy())
+        else:
+            m._input_quantizer._amax = torch.from_numpy(np.asarray(d["x"], np.float32).reshape(-1).copy())
+            m._weight_quantizer._amax = torch.from_numpy(np.asarray(d["w"], np.float32).reshape(-1).copy())
+    Qz._touch()
+
+
+@pytest.mark.parametrize("shrink", [1.0, 0.5])
+def test_static_ptq_parity_with_the_oracle(dev, shrink):
+    """quant(..., static=True) against oracle.centerpoint.calibrate / Recipe(static=...):
+      (a) every quantizer's calibrated amax (running max over the calibration frames of what it sees in the fp32 forward);
+      (b) the static forward, teacher-forced layer by layer on a frame that was NOT in the calibration set, so values beyond
+          the calibrated range clip at -128 / 127; shrink = 0.5 halves every amax to make clipping the common case."""
+    import teacher
+    from amdq3d import quant as Qz
+    from amdq3d.datasets import load_data_to_gpu
+    cfg = small_cfg("waymo")
+    ds, model = build_model(cfg, n_points=7000, n_voxels=2000, n_frames=3)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.cuda()
+    loader = [ds.collate_batch([ds[i]]) for i in (1, 2)]
+    Qz.quant(model, 8, 8, sq=True, alpha=0.5, static=True, test_loader=loader, n_batches=5)
+    rec = OC.Recipe(8, 8, True, 0.5)
+    static = OC.calibrate(state, cfg, [ds[i]["points"] for i in (1, 2)], rec)
+    mods = dict(model.named_modules())
+    assert len(static) == 37
+    for path, d in static.items():
+        m = mods[path]
+        if "act" in d:
+            np.testing.assert_allclose(m.act_quant.amax.numpy(), d["act"], rtol=2e-5, atol=1e-7, err_msg=path)
+        else:
+            np.testing.assert_allclose(m._input_quantizer.amax.numpy().reshape(-1), np.asarray(d["x"]).reshape(-1), rtol=2e-5, err_msg=path)
+            np.testing.assert_allclose(m._weight_quantizer.amax.numpy(), d["w"], rtol=2e-5, atol=1e-7, err_msg=path)
+    if shrink != 1.0:
+        static = {p: {k: np.asarray(v, np.float32) * np.float32(shrink) for k, v in d.items()} for p, d in static.items()}
+    _set_static(model, static, Qz)                         # identical amax on both sides: codes must agree bit for bit
+    batch = ds.collate_batch([ds[0]]); load_data_to_gpu(batch, dev)
+    with torch.no_grad():
+        model(batch)
+    trace = {}
+    OC.run(state, cfg, ds[0]["points"], OC.Recipe(8, 8, True, 0.5, static=static), trace)
+    # clipping is exercised: the test frame exceeds the calibrated range somewhere
+    x1 = trace["backbone_3d.conv_input.0"]
+    clipped = int((np.abs(x1) > np.asarray(static["backbone_3d.conv1.0.conv1"]["act"])[None, :]).sum())
+    assert clipped > 0
+    eng = model.engine()
+    idx_sets = [trace["vfe"][1]] + [trace["levels"][n][1] for n in ("x_conv2", "x_conv3", "x_conv4")] + [trace["encoded"][1]]
+    maps = teacher.row_maps(eng, idx_sets)
+    res = teacher.sparse_layers(eng, maps, lambda n: trace["vfe"][0] if n == "vfe" else trace[n])
+    res += teacher.dense_layers(eng, lambda n: trace[n])
+    teacher.report("static PTQ (amax x %.1f), teacher-forced layers; %d first-layer inputs beyond the calibrated range" % (shrink, clipped), res)
+    bad = [(p, e) for p, k, e, _ in res if not e <= 2e-5]
+    assert not bad, bad
