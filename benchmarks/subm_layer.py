@@ -5,8 +5,10 @@ kernel sits against the HBM / MFMA roofs once launch latency stops dominating (S
 
     python benchmarks/subm_layer.py [--channels 16 64 128] [--voxels 30000 120000 480000 1000000] [--occupancy sheet|w150k]
 
-Prints one JSON line per (channels, voxels). Timed region: aq3d_quantize_rows (per-channel quantiser + fp16 split) +
-aq3d_spconv (fused bias/BN/ReLU epilogue) with the gather table already built, HIP events over `--iters` launches.
+Prints one JSON line per (channels, voxels). Timed region: aq3d_spconv_prep (per-channel quantiser to int8 codes + per-frame
+weight copy) + aq3d_spconv_coded (fused bias/BN/ReLU epilogue) with the gather table already built, HIP events over `--iters`
+launches; the two kernels are also timed separately. Algorithmic bytes: fp32 rows in + codes out (quantiser), codes + gather
+table + int8 weights in, fp32 rows out (conv).
 """
 import argparse
 import json
@@ -69,6 +71,7 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--order", default="random", choices=["random", "morton", "linear"], help="row order of the voxels")
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle on the smallest size")
+    ap.add_argument("--tile-order", action="store_true", help="rows grouped by neighbour pattern (aq3d_tile_order) before the conv")
     args = ap.parse_args()
     from amdq3d import ops
     from oracle import sparse as OS
@@ -89,33 +92,48 @@ def main():
             w = torch.randn(C, 3, 3, 3, C, generator=g) / np.sqrt(13 * C)
             wq, codes, wdiv = OS.qconv_weight(w.numpy(), 8)
             wk = torch.from_numpy(np.ascontiguousarray(codes.reshape(C, 27, C).transpose(1, 0, 2))).to(dev)
-            w16 = wk.to(torch.float16)
+            wk8 = wk.to(torch.int8)
             wdq = torch.from_numpy((np.float32(1) / wdiv).astype(np.float32)).to(dev)
             ps, pt = torch.ones(C, device=dev), torch.zeros(C, device=dev)
             amax = ops.absmax_cols(x, count)
             out = torch.empty((cap, C), device=dev)
             am_out = torch.zeros(C, device=dev)
+            bufs = (torch.zeros((cap, C), dtype=torch.int8, device=dev), torch.empty((27, C, 2, C), dtype=torch.float16, device=dev),
+                    torch.empty((C,), device=dev))
+            perm = nbr_t = None
+            if args.tile_order:
+                perm, nbr_t = ops.tile_order(nbr, count)
 
-            def layer():
-                _, _, _, split = ops.quantize_rows(x, amax, count, want_codes=False, want_split=True)
-                return ops.spconv(split, w16, nbr, count, C, w_dequant=wdq, post_scale=ps, post_shift=pt, relu=True,
-                                  absmax_out=am_out, out=out)
-            for _ in range(5):
-                layer()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(args.iters):
-                layer()
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / args.iters
-            byts = m * C * 4 + m * C * 1 + m * C * 4 + 27 * C * C + m * 27 * 4      # fp32 in (quantiser) + codes + fp32 out + w + table
+            def prep():
+                ops.spconv_prep(x, amax, count, wk8, wdq, out=bufs)
+
+            def conv():
+                return ops.spconv_coded(bufs[0], bufs[1], bufs[2], nbr_t if perm is not None else nbr, count, perm=perm,
+                                        post_scale=ps, post_shift=pt, relu=True, absmax_out=am_out, out=out)
+
+            def timed(fn):
+                for _ in range(5):
+                    fn()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(args.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / args.iters
+
+            us_prep, us_conv = timed(prep), timed(conv)
+            us = timed(lambda: (prep(), conv()))
+            b_prep = m * C * 5 + 27 * C * C * 5
+            b_conv = m * C * 1 + m * C * 4 + 27 * C * C + m * 27 * 4
+            byts = b_prep + b_conv
             flops = 2.0 * pairs * C * C
             rec = {"layer": "SubMConv3d 3x3x3 %d->%d int8-w x per-channel-quantised a" % (C, C), "occupancy": args.occupancy, "order": args.order,
-                   "voxels": m, "pairs": pairs, "us_per_layer": us, "algorithmic_GBps": byts / us / 1e3,
-                   "frac_hbm": byts / us / 1e3 / HBM_GBS, "useful_TFLOPs": flops / us / 1e6,
-                   "frac_mfma_f16": flops / us / 1e6 / F16_TFLOPS, "voxels_per_s": m / us * 1e6}
+                   "tile_order": bool(args.tile_order), "voxels": m, "pairs": pairs, "us_per_layer": us, "us_prep": us_prep, "us_conv": us_conv,
+                   "algorithmic_bytes": byts, "algorithmic_GBps": byts / us / 1e3, "frac_hbm": byts / us / 1e3 / HBM_GBS,
+                   "conv_only_GBps": b_conv / us_conv / 1e3, "conv_only_frac_hbm": b_conv / us_conv / 1e3 / HBM_GBS,
+                   "useful_TFLOPs": flops / us / 1e6, "frac_mfma_f16": 2 * flops / us_conv / 1e6 / F16_TFLOPS, "voxels_per_s": m / us * 1e6}
             if args.cpu and m_req == args.voxels[0]:
                 xa, _ = OS.qconv_act(x.cpu().numpy(), 8, cw=True)
                 nb = nbr.cpu().numpy()

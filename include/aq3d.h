@@ -139,35 +139,32 @@ int aq3d_absmax_cols(const float *x, const int32_t *count, int32_t cap, int32_t 
 
 /* TensorQuantizer(axis=1) on rows: scale_c = qmax/amax_c; q = clamp(rint(x*scale_c), -qmax-1, qmax).
  *   codes_out  i8  [cap, C] integer codes (may be NULL; only for bits <= 8)
- *   fq_out     f32 [cap, C] fake-quantized values q/scale_c (may be NULL)
+ *   fq_out     f32 [cap, C] fake-quantized values q/scale_c (may be NULL) — the fp32 fallback of layers the coded path does
+ *                           not take (act_bits = 16, unusual channel counts)
  *   dequant_out f32 [C]     1/scale_c                      (may be NULL)
- *   split_out  f16 [cap, 2C] the fake-quantized value v = q/scale_c as an fp16 pair, row = [hi(C) | lo(C)],
- *                           hi = fp16(v), lo = fp16((v - hi) * 2048): v = hi + lo/2048 to 22 bits (may be NULL)
  *   per_tensor != 0: one amax = max_c amax_c is used for every column (QuantDescriptor without axis). */
 int aq3d_quantize_rows(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C,
                        int32_t bits, int32_t per_tensor, int8_t *codes_out, float *fq_out,
-                       float *dequant_out, void *split_out, void *stream);
+                       float *dequant_out, void *stream);
 
 enum {
     AQ3D_ACT_F32 = 0,  /* feats_in is f32 [*, Cin] used as is                       */
-    AQ3D_ACT_I8 = 1,   /* feats_in is i8 codes [*, Cin]; value = code * act_dequant[c] (scale folded into the gather) */
-    AQ3D_ACT_F16SPLIT = 2 /* feats_in is the f16 [*, 2*Cin] hi|lo pair written by aq3d_quantize_rows(split_out) */
+    AQ3D_ACT_I8 = 1    /* feats_in is i8 codes [*, Cin]; value = code * act_dequant[c] (generic kernel; production: aq3d_spconv_coded) */
 };
 enum {
     AQ3D_W_F32 = 0,    /* weight is f32 [kvol, Cout, Cin]                           */
-    AQ3D_W_I8 = 1,     /* weight is i8 codes [kvol, Cout, Cin]; value = code * w_dequant[cout] */
-    AQ3D_W_F16 = 2     /* weight is the same integer codes held as f16 [kvol, Cout, Cin]; value = code * w_dequant[cout] */
+    AQ3D_W_I8 = 1      /* weight is i8 codes [kvol, Cout, Cin]; value = code * w_dequant[cout] */
 };
 enum { AQ3D_FLAG_RELU = 1 };
 
 /*
- * Output-stationary gather-GEMM sparse convolution with fused epilogue:
+ * Output-stationary gather-GEMM sparse convolution with fused epilogue (fp32 layers — conv_input, unquantised models — and
+ * weight-only layers; the w8a8 QConvNd layers run through aq3d_spconv_prep + aq3d_spconv_coded below):
  *   acc[m,o]  = sum_k sum_c A[nbr[m][k], c] * W[k][c][o]                  (fp32 accumulate, MFMA)
  *   y[m,o]    = (acc * w_dequant[o] + bias[o]) * post_scale[o] + post_shift[o]   (bias / post_* may be NULL)
  *   y        += residual[m,o]                                              (may be NULL)
  *   y         = max(y, 0) if flags & AQ3D_FLAG_RELU
  *   absmax_out[o] = max(absmax_out[o], |y[m,o]|) over m                    (may be NULL; caller zeroes it)
- * cap_in = rows of the feats_in buffer (bounds of the hardware-checked loads of the f16-split path).
  */
 int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant,
                 const void *weight, int32_t w_mode, const float *w_dequant,
@@ -175,17 +172,6 @@ int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant
                 const float *residual, const int32_t *nbr, const int32_t *count_out, int32_t cap_out, int32_t cap_in,
                 int32_t cin, int32_t cout, int32_t kvol, int32_t flags,
                 float *feats_out, float *absmax_out, void *stream);
-
-/* aq3d_spconv with an optional scratch buffer (aq3d_spconv_workspace_bytes; ZEROED ONCE by the caller, the library keeps it
- * consistent afterwards; one launch at a time per buffer). With it, the wide-tile f16-split kernel lets two workgroups share
- * a 128-row tile (half of the kernel offsets each) while the live row count leaves CUs idle — decided on the device. */
-size_t aq3d_spconv_workspace_bytes(int32_t cap_out, int32_t cout);
-int aq3d_spconv_ws(const void *feats_in, int32_t act_mode, const float *act_dequant,
-                   const void *weight, int32_t w_mode, const float *w_dequant,
-                   const float *bias, const float *post_scale, const float *post_shift, const float *residual,
-                   const int32_t *nbr, const int32_t *count_out, int32_t cap_out, int32_t cap_in,
-                   int32_t cin, int32_t cout, int32_t kvol, int32_t flags,
-                   float *feats_out, float *absmax_out, void *workspace, size_t workspace_bytes, void *stream);
 
 /* One layer of a grouped aq3d_spconv launch (the pointer arguments of aq3d_spconv). */
 typedef struct aq3d_spconv_problem {
@@ -198,14 +184,13 @@ typedef struct aq3d_spconv_problem {
 } aq3d_spconv_problem;
 
 /* Up to 8 sparse convs of one shape (cin, cout, kvol, modes, capacities) as ONE launch — the per-branch SubMConv2d stacks of
- * VoxelNeXtHead's SeparateHead (pcdet/models/dense_heads/voxelnext_head.py:13-47). Modes: f32 / int8-coded operands (the
- * f16-split path takes one layer per call). */
+ * VoxelNeXtHead's SeparateHead (pcdet/models/dense_heads/voxelnext_head.py:13-47). */
 int aq3d_spconv_group(const aq3d_spconv_problem *problems, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
                       int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, void *stream);
 
 /* ------------- production path of the QConvNd layers: int8-coded activations, scale folded into a per-frame weight copy ----
- * Replaces, for quant/quant.py:36-58 (QConvNd.forward) around the spconv call sites pcdet/models/backbones_3d/
- * spconv_backbone.py:12-17,39-46, the pair aq3d_quantize_rows(split_out) + aq3d_spconv(AQ3D_ACT_F16SPLIT):
+ * Replaces quant/quant.py:36-58 (QConvNd.forward) around the spconv call sites pcdet/models/backbones_3d/
+ * spconv_backbone.py:12-17,39-46:
  *   y[m,o] = sum_{k,c} (q[nbr[m][k],c] * d_c) * (wq[k,o,c] * t_o) = (sum q * W') * (S * t_o),  W' = wq * (d_c / S), S = max_c d_c.
  * aq3d_spconv_prep (ONE launch): TensorQuantizer(axis=1) of x f32 [*count, C] with the given abs-max -> codes_out i8 [cap, C]
  *   (1 byte per element; for C >= 64 the bytes of every 64-channel group are permuted, an internal layout only

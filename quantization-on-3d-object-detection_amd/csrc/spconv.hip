@@ -395,7 +395,7 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, dim3(grid, n), dim3(256), lds, stream, grp);                                   \
     } while (0)
-    static const bool f16w = !(getenv("AQ3D_SPCONV_F16W") && atoi(getenv("AQ3D_SPCONV_F16W")) == 0);
+    const bool f16w = true;
     if constexpr (CIN_PAD % 32 == 0) {
         if (f16w && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_I8 && a.cin == CIN_PAD) {
             bool same = true;
@@ -419,23 +419,6 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
     AQ3D_CHECK_LAUNCH("aq3d_spconv");
     return AQ3D_OK;
 }
-
-int aq3d_spconv_i8_dispatch(const int8_t *feats_in, const float *act_dequant, const int8_t *weight, const float *w_dequant,
-                            const float *bias, const float *post_scale, const float *post_shift, const float *residual,
-                            const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
-                            float *feats_out, float *absmax_out, hipStream_t stream);
-int aq3d_spconv_direct_dispatch(const void *feats_split, unsigned feats_bytes, const void *weight_f16, const float *w_dequant,
-                                const float *bias, const float *post_scale, const float *post_shift, const float *residual,
-                                const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
-                                float *feats_out, float *absmax_out, hipStream_t stream);
-int aq3d_spconv_wide_dispatch(const void *feats_split, unsigned feats_bytes, const void *weight_f16, const float *w_dequant,
-                              const float *bias, const float *post_scale, const float *post_shift, const float *residual,
-                              const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
-                              float *feats_out, float *absmax_out, void *ws, size_t ws_bytes, hipStream_t stream);
-int aq3d_spconv_split_dispatch(const void *feats_split, unsigned feats_bytes, const void *weight_f16, const float *w_dequant,
-                               const float *bias, const float *post_scale, const float *post_shift, const float *residual,
-                               const int *nbr, const int *count_out, int cap_out, int cin, int cout, int kvol, int relu,
-                               float *feats_out, float *absmax_out, hipStream_t stream);
 
 // ---------------------------------------------------------------- stem layer (conv_input: Cin <= 8 raw point features -> 16)
 // K = 27 * Cin is ~135: far too thin for tiles, LDS staging and barriers (the generic kernel takes 42 us for 30 k rows, all of
@@ -516,68 +499,17 @@ __global__ __launch_bounds__(256) void spconv_stem_kernel(SpconvArgs a, int cout
 extern "C" int aq3d_spconv_group(const aq3d_spconv_problem *probs, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
                                  int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, void *stream_);
 
-extern "C" int aq3d_spconv_ws(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
-                              int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
-                              const float *post_shift, const float *residual, const int32_t *nbr,
-                              const int32_t *count_out, int32_t cap_out, int32_t cap_in, int32_t cin, int32_t cout,
-                              int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, void *workspace,
-                              size_t workspace_bytes, void *stream_);
-
-extern "C" size_t aq3d_spconv_workspace_bytes(int32_t cap_out, int32_t cout) {
-    if (cap_out < 1 || cout < 1) return 0;
-    const size_t tiles = (size_t)aq3d_div_up(cap_out, 128);
-    return ((tiles * 4 + 255) & ~(size_t)255) + tiles * 2 * 128 * (size_t)cout * 4;
-}
-
 extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
                            int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
                            const float *post_shift, const float *residual, const int32_t *nbr,
                            const int32_t *count_out, int32_t cap_out, int32_t cap_in, int32_t cin, int32_t cout,
                            int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, void *stream_) {
-    return aq3d_spconv_ws(feats_in, act_mode, act_dequant, weight, w_mode, w_dequant, bias, post_scale, post_shift, residual, nbr,
-                          count_out, cap_out, cap_in, cin, cout, kvol, flags, feats_out, absmax_out, nullptr, 0, stream_);
-}
-
-extern "C" int aq3d_spconv_ws(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
-                              int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
-                              const float *post_shift, const float *residual, const int32_t *nbr,
-                              const int32_t *count_out, int32_t cap_out, int32_t cap_in, int32_t cin, int32_t cout,
-                              int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, void *workspace,
-                              size_t workspace_bytes, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     AQ3D_REQUIRE(feats_in && weight && nbr && count_out && feats_out, "aq3d_spconv: null argument");
     AQ3D_REQUIRE(cap_out > 0 && kvol >= 1 && kvol <= 27, "aq3d_spconv: cap_out=%d kvol=%d", cap_out, kvol);
     AQ3D_REQUIRE(cin >= 1 && cin <= 128, "aq3d_spconv: cin=%d not in 1..128", cin);
     AQ3D_REQUIRE(act_mode != AQ3D_ACT_I8 || ((cin % 16) == 0 && act_dequant), "aq3d_spconv: int8 activations need cin%%16==0 and act_dequant");
     AQ3D_REQUIRE(w_mode != AQ3D_W_I8 || ((cin % 16) == 0 && w_dequant), "aq3d_spconv: int8 weights need cin%%16==0 and w_dequant");
     AQ3D_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "aq3d_spconv: post_scale/post_shift must come together");
-    if (act_mode == AQ3D_ACT_F16SPLIT || w_mode == AQ3D_W_F16) {
-        AQ3D_REQUIRE(act_mode == AQ3D_ACT_F16SPLIT && w_mode == AQ3D_W_F16 && w_dequant,
-                     "aq3d_spconv: f16-split activations go with f16 weight codes (+ w_dequant)");
-        AQ3D_REQUIRE(cap_in > 0 && (int64_t)cap_in * cin * 4 < (int64_t)0xfffffff0, "aq3d_spconv: cap_in=%d needed (and < 4 GiB of features) for the f16-split path", cap_in);
-        {
-            int rc = aq3d_spconv_direct_dispatch(feats_in, (unsigned)((int64_t)cap_in * cin * 4), weight, w_dequant, bias,
-                                                 post_scale, post_shift, residual, nbr, count_out, cap_out, cin, cout, kvol,
-                                                 (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, stream);
-            if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
-            rc = aq3d_spconv_wide_dispatch(feats_in, (unsigned)((int64_t)cap_in * cin * 4), weight, w_dequant, bias,
-                                           post_scale, post_shift, residual, nbr, count_out, cap_out, cin, cout, kvol,
-                                           (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, workspace, workspace_bytes, stream);
-            if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
-        }
-        return aq3d_spconv_split_dispatch(feats_in, (unsigned)((int64_t)cap_in * cin * 4), weight, w_dequant, bias, post_scale,
-                                          post_shift, residual, nbr, count_out, cap_out, cin, cout, kvol,
-                                          (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, stream);
-    }
-    if (act_mode == AQ3D_ACT_I8 && w_mode == AQ3D_W_I8) {
-        static const bool force_f32 = getenv("AQ3D_SPCONV_F32MFMA") != nullptr;   // A/B switch: exact-f32 MFMA path
-        if (!force_f32) {
-            int rc = aq3d_spconv_i8_dispatch((const int8_t *)feats_in, act_dequant, (const int8_t *)weight, w_dequant, bias,
-                                             post_scale, post_shift, residual, nbr, count_out, cap_out, cin, cout, kvol,
-                                             (flags & AQ3D_FLAG_RELU) ? 1 : 0, feats_out, absmax_out, stream);
-            if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
-        }
-    }
     aq3d_spconv_problem q;
     q.feats_in = feats_in; q.act_dequant = act_dequant; q.weight = weight; q.w_dequant = w_dequant; q.bias = bias;
     q.post_scale = post_scale; q.post_shift = post_shift; q.residual = residual; q.nbr = nbr; q.count_out = count_out;
@@ -590,7 +522,6 @@ extern "C" int aq3d_spconv_group(const aq3d_spconv_problem *probs, int32_t n, in
     hipStream_t stream = (hipStream_t)stream_;
     (void)cap_in;
     AQ3D_REQUIRE(probs && n >= 1 && n <= AQ3D_SPCONV_MAX_GROUP, "aq3d_spconv_group: n=%d not in 1..%d", n, AQ3D_SPCONV_MAX_GROUP);
-    AQ3D_REQUIRE(act_mode != AQ3D_ACT_F16SPLIT && w_mode != AQ3D_W_F16, "aq3d_spconv_group: the f16-split path takes one layer per call (aq3d_spconv)");
     AQ3D_REQUIRE(cap_out > 0 && kvol >= 1 && kvol <= 27, "aq3d_spconv: cap_out=%d kvol=%d", cap_out, kvol);
     AQ3D_REQUIRE(cin >= 1 && cin <= 128, "aq3d_spconv: cin=%d not in 1..128", cin);
     SpconvGroup grp;
@@ -608,17 +539,7 @@ extern "C" int aq3d_spconv_group(const aq3d_spconv_problem *probs, int32_t n, in
     }
     for (int i = n; i < AQ3D_SPCONV_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     const SpconvArgs &a = grp.p[0];
-    if (n == 1 && act_mode == AQ3D_ACT_I8 && w_mode == AQ3D_W_I8) {
-        static const bool force_f32 = getenv("AQ3D_SPCONV_F32MFMA") != nullptr;   // A/B switch: exact-f32 MFMA path
-        if (!force_f32) {
-            int rc = aq3d_spconv_i8_dispatch((const int8_t *)a.feats_in, a.act_dequant, (const int8_t *)a.weight, a.w_dequant, a.bias,
-                                             a.post_scale, a.post_shift, a.residual, a.nbr, a.count_out, cap_out, cin, cout, kvol,
-                                             a.relu, a.feats_out, a.absmax_out, stream);
-            if (rc != AQ3D_ERR_UNSUPPORTED) return rc;
-        }
-    }
-    static const bool no_stem = getenv("AQ3D_SPCONV_NO_STEM") != nullptr;
-    if (n == 1 && !no_stem && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && cin <= 8 && (cout & 3) == 0 && cout <= 64) {
+    if (n == 1 && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && cin <= 8 && (cout & 3) == 0 && cout <= 64) {
         const dim3 grid(aq3d_div_up(cap_out, 256), cout / 4);
         switch (cin) {
 #define AQ3D_STEM(C_) case C_: hipLaunchKernelGGL(spconv_stem_kernel<C_>, grid, dim3(256), 0, stream, a, cout); break;
@@ -682,8 +603,7 @@ extern "C" int aq3d_absmax_cols(const float *x, const int32_t *count, int32_t ca
 __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restrict__ x, const float *__restrict__ amax,
                                                             const int *count, int cap, int C, float qmax,
                                                             int per_tensor, int8_t *__restrict__ codes,
-                                                            float *__restrict__ fq, float *__restrict__ dequant,
-                                                            _Float16 *__restrict__ split) {
+                                                            float *__restrict__ fq, float *__restrict__ dequant) {
     __shared__ float s_scale[256];
     __shared__ float s_div[256];
     int n = *count;
@@ -722,18 +642,6 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restr
             }
             if (codes) reinterpret_cast<char4 *>(codes)[t] = make_char4(qc[0], qc[1], qc[2], qc[3]);
             if (fq) reinterpret_cast<float4 *>(fq)[t] = make_float4(v[0], v[1], v[2], v[3]);
-            if (split) {
-                _Float16 h[4], l[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    h[k] = (_Float16)v[k];
-                    l[k] = (_Float16)__fmul_rn(__fsub_rn(v[k], (float)h[k]), 2048.f);
-                }
-                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-                h4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
-                *reinterpret_cast<h4 *>(split + (size_t)r * 2 * C + c) = hv;
-                *reinterpret_cast<h4 *>(split + (size_t)r * 2 * C + C + c) = lv;
-            }
         }
         return;
     }
@@ -745,18 +653,12 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float *__restr
         if (codes) codes[t] = (int8_t)(int)q;
         const float v = __fdiv_rn(q, s_div[c]);
         if (fq) fq[t] = v;
-        if (split) {
-            const long long r = t / C;
-            const _Float16 h = (_Float16)v;
-            split[r * 2 * C + c] = h;
-            split[r * 2 * C + C + c] = (_Float16)__fmul_rn(__fsub_rn(v, (float)h), 2048.f);
-        }
     }
 }
 
 extern "C" int aq3d_quantize_rows(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C,
                                   int32_t bits, int32_t per_tensor, int8_t *codes_out, float *fq_out,
-                                  float *dequant_out, void *split_out, void *stream_) {
+                                  float *dequant_out, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AQ3D_REQUIRE(x && amax && count, "aq3d_quantize_rows: null argument");
     AQ3D_REQUIRE(C >= 1 && C <= 256, "aq3d_quantize_rows: C=%d not in 1..256", C);
@@ -764,7 +666,7 @@ extern "C" int aq3d_quantize_rows(const float *x, const float *amax, const int32
     AQ3D_REQUIRE(!(codes_out && bits > 8), "aq3d_quantize_rows: int8 codes need bits <= 8");
     const float qmax = (float)((1 << (bits - 1)) - 1);
     hipLaunchKernelGGL(quantize_rows_kernel, dim3(aq3d_grid((int64_t)cap * C / ((C & 3) == 0 ? 4 : 1), 256)), dim3(256), 0, stream, x, amax, count,
-                       cap, C, qmax, per_tensor, codes_out, fq_out, dequant_out, (_Float16 *)split_out);
+                       cap, C, qmax, per_tensor, codes_out, fq_out, dequant_out);
     AQ3D_CHECK_LAUNCH("aq3d_quantize_rows");
     return AQ3D_OK;
 }

@@ -128,7 +128,11 @@ __global__ __launch_bounds__(256) void sp_prep_kernel(SpPrepArgs a) {
         for (int i = 0; i < 8; ++i) {
             const int code = (int)(signed char)((i < 4 ? wv.x : wv.y) >> (8 * (i & 3)));
             const float rel = __fdiv_rn(s_dq[c0 + i], S);
-            const float v = __fmul_rn((float)code, rel);
+            float v = __fmul_rn((float)code, rel);
+            // v has to exist as ONE rounded fp32 value: without the barrier the backend folds (half)(code * rel) into a
+            // mixed-precision fma (v_fma_mixlo_f16, a single rounding of the exact product) for one use of `h` and keeps
+            // cvt(fp32 product) for the other — hi + lo then misses v by an fp16 ulp of hi (seen as 3e-2 absolute on |W'| ~ 100)
+            asm volatile("" : "+v"(v));
             const _Float16 h = (_Float16)v;
             hi[i] = h;
             lo[i] = (_Float16)__fsub_rn(v, (float)h);
@@ -558,7 +562,7 @@ extern "C" int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void
     a.relu = (flags & AQ3D_FLAG_RELU) ? 1 : 0;
     a.codes_bytes = (unsigned)((int64_t)cap_in * cin);
     if (cin == 16 && cout == 16) return launch_cd<16, 27, 4>(a, stream);
-    if (cin == 16 && cout == 32) return launch_cd<32, 27, 4>(a, stream);
+    if (cin == 16 && cout == 32) return launch_cd<32, 27, 8>(a, stream);    // 58 KB of W' per workgroup: 8 waves share it
     if (cin == 32 && cout == 32) return launch_cw<32, 32>(a, stream);
     if (cin == 32 && cout == 64) return launch_cw<32, 64>(a, stream);
     if (cin == 64 && cout == 64) return launch_cw<64, 64>(a, stream);

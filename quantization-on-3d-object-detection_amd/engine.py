@@ -132,19 +132,14 @@ class Engine:
         self.max_voxels = int(vcfg.MAX_NUMBER_OF_VOXELS["test"])
         cap_opt = getattr(det, "voxel_capacity", None)
         self.cap = int(cap_opt) if cap_opt else self.max_voxels * self.batch_cap
-        # "coded" (int8 codes in HBM, scale folded into a per-frame fp16 hi|lo weight copy: csrc/spconv_coded.hip) |
-        # "split" (round-1 format: fp16 hi|lo activations) | "i8" (round-1 coded gather with LDS staging)
-        self.spconv_mode = os.environ.get("AQ3D_SPCONV_MODE", "coded")
-        # rows of the gather tables grouped by neighbour pattern so that 128-row tiles skip kernel offsets (csrc/tile_order.hip).
-        # Measured on W150k (profiles/r02_*): the 128-channel SubM layers go 110 -> 96 us, the 64->128 strided conv 67 -> 49 us,
-        # the narrower levels do not move (they are not bound by the matrix pipe), and the LDS sort costs 360 us per table on
-        # the index stream — a net loss at this frame size (396 vs 575 frames/s with all nine tables sorted), so it is opt-in.
-        self.tile_order = os.environ.get("AQ3D_TILE_ORDER", "0") != "0"
+        # rows of the gather tables grouped by neighbour pattern so that 128-row tiles skip kernel offsets (csrc/tile_order.hip):
+        # "0" off, "1" every table read by a coded conv, "auto" only the tables of 128-output-channel 3x3x3 convs (the layers
+        # bound by the matrix pipe; the LDS sort costs ~0.36 ms per table on the index stream)
+        self.tile_order = os.environ.get("AQ3D_TILE_ORDER", "0")
         self.arena = _Arena(device)
         self.steps = []
         self.tensors = {}
         self._voxel_ws = None
-        self._sp_ws = None
         if isinstance(det.backbone_3d, VoxelResBackBone8xVoxelNeXt):
             self.fully_sparse = True
             self._build_voxelnext(det.backbone_3d, det.dense_head)
@@ -231,9 +226,7 @@ class Engine:
             if wq_desc.w_bits <= 8 and cin % 16 == 0:
                 wk = np.transpose(padc(codes.astype(np.float32)), (1, 0, 2))
                 rec["weight_i8"] = self._dev(wk.astype(np.int8))              # canonical int8 codes [kvol, cout, cin]
-                # staging copy of the same integers as fp16 (exact): the split-activation kernel copies it verbatim
-                split_w = q is not None and self.spconv_mode in ("split", "coded")
-                rec["weight"] = self._dev(wk.astype(np.float16)) if split_w else rec["weight_i8"]
+                rec["weight"] = rec["weight_i8"]
                 rec["w_dequant"] = self._dev(padc(wdq, 1.0))
             else:   # fake-quantised fp32 weights through the fp32 weight path
                 wfq = (codes.astype(np.float32) * wdq[:, None, None]).astype(np.float32)
@@ -253,19 +246,20 @@ class Engine:
             rec["quant"] = dict(bits=q.act_bits, per_tensor=not q.cw, quantizer=aq, on=aq._if_quant,
                                 calib=aq._if_calib,
                                 static_amax=None if aq.amax is None else self._dev(_np(aq.amax).reshape(-1)))
-            use_codes = q.act_bits <= 8 and cin % 16 == 0 and rec["w_dequant"] is not None
-            rec["quant"]["use_codes"] = use_codes
-            coded = use_codes and self.spconv_mode == "coded" and ops.spconv_coded_supported(cin, cout, kvol)
-            split = use_codes and not coded and self.spconv_mode in ("split", "coded")
-            rec["coded"] = coded
+            # production: int8 codes in HBM + per-frame weight copy (csrc/spconv_coded.hip); anything that path does not take
+            # (act_bits = 16, channel counts it has no variant for) runs on fp32 fake-quantised rows through aq3d_spconv
+            coded = q.act_bits <= 8 and rec["w_dequant"] is not None and ops.spconv_coded_supported(cin, cout, kvol)
+            rec["coded"] = rec["quant"]["use_codes"] = coded
             if coded:
-                self._request_tile_order(nbr)       # per-frame weight copy W' = code * (d_c / S) as fp16 hi | lo planes + epilogue multipliers S * t_o
+                if self.tile_order == "1" or (self.tile_order == "auto" and cout == 128 and kvol == 27):
+                    self._request_tile_order(nbr)
+                rec["codes"] = torch.zeros((cap, cin), dtype=torch.int8, device=dev)
+                # W' = code * (d_c / S) as fp16 hi | lo planes + epilogue multipliers S * t_o, rebuilt per frame by aq3d_spconv_prep
                 rec["wprep"] = torch.zeros((kvol, cout, 2, cin), dtype=torch.float16, device=dev)
                 rec["out_mul"] = torch.zeros((cout,), dtype=f32, device=dev)
-            rec["split"] = torch.zeros((cap, 2 * cin), dtype=torch.float16, device=dev) if split else None
-            rec["codes"] = torch.zeros((cap, cin), dtype=torch.int8, device=dev) if use_codes and not split else None
-            rec["fq"] = None if use_codes else torch.zeros((cap, cin), dtype=f32, device=dev)
-            rec["dq"] = torch.zeros((cin,), dtype=f32, device=dev)
+            else:
+                rec["fq"] = torch.zeros((cap, cin), dtype=f32, device=dev)
+                rec["dq"] = torch.zeros((cin,), dtype=f32, device=dev)
         out = self._tensor(level_out, cout, path)
         rec["out"] = out
         self.sparse_convs.append(rec)
@@ -868,8 +862,6 @@ class Engine:
 
     def _request_tile_order(self, ref):
         """Compile time: the coded convs that read this table want it in tile order (buffers + an index-phase step)."""
-        if not self.tile_order:
-            return
         holder = self.levels[ref[1]]["down"] if isinstance(ref, tuple) else self.levels[ref]
         if isinstance(ref, tuple) and ref[0] != "down":
             return
@@ -877,13 +869,6 @@ class Engine:
             nbr = holder["nbr"]
             holder["tiled"] = dict(nbr=torch.full(tuple(nbr.shape), -1, dtype=i32, device=self.device),
                                    perm=torch.zeros((self.cap,), dtype=i32, device=self.device))
-
-    def _spconv_ws(self):
-        """Scratch for the split-tile mode of the wide kernel (AQ3D_WIDE_SPLIT=1; measured SLOWER than whole tiles — the doubled
-        prologue, the 64 KB accumulator hand-over and co-residency cost more than the idle CUs — so it is off by default)."""
-        if self._sp_ws is None:
-            self._sp_ws = ops.spconv_workspace(self.cap, 128, self.device) if os.environ.get("AQ3D_WIDE_SPLIT", "0") != "0" else False
-        return self._sp_ws if self._sp_ws is not False else None
 
     def _run_spconv(self, rec):
         lv = self.levels[rec["level"]]
@@ -914,20 +899,15 @@ class Engine:
             L = ops._lib.load()
             with _Timed(self, "quantize_rows"):
                 ops.check(L.aq3d_quantize_rows(ops._p(x["buf"]), ops._p(amax), ops._p(in_count), self.cap, x["C"], q["bits"],
-                                               int(q["per_tensor"]), ops._p(rec["codes"]), ops._p(rec["fq"]), ops._p(rec["dq"]),
-                                               ops._p(rec["split"]), ops._stream()), "aq3d_quantize_rows")
-            if rec["split"] is not None:
-                feats = rec["split"]
-            elif q["use_codes"]:
-                feats, act_dq = rec["codes"], rec["dq"]
-            else:
-                feats = rec["fq"]
+                                               int(q["per_tensor"]), None, ops._p(rec["fq"]), ops._p(rec["dq"]), ops._stream()),
+                          "aq3d_quantize_rows")
+            feats = rec["fq"]
         out = rec["out"]
         with _Timed(self, "spconv_c%d" % rec["cout"]):
             ops.spconv(feats, rec["weight"], nbr, lv["count"], rec["cout"], act_dequant=act_dq, w_dequant=rec["w_dequant"],
                        bias=rec["bias"], post_scale=rec["post_scale"], post_shift=rec["post_shift"],
                        residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
-                       absmax_out=self.arena.view(out["amax"]), out=out["buf"], workspace=self._spconv_ws())
+                       absmax_out=self.arena.view(out["amax"]), out=out["buf"])
 
     def _run_conv2d(self, rec, B):
         g = rec["geom"]

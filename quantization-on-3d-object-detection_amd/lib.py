@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class Aq3dError(RuntimeError):
@@ -70,7 +70,7 @@ SIGNATURES = {
                                     P, c_size_t, P]),
     "aq3d_tile_order": (c_int32, [P, P, c_int32, c_int32, P, P, P]),
     "aq3d_absmax_cols": (c_int32, [P, P, c_int32, c_int32, P, P]),
-    "aq3d_quantize_rows": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, P, P, P, P, P]),
+    "aq3d_quantize_rows": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
     "aq3d_spconv": (c_int32, [P, c_int32, P, P, c_int32, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32,
                               c_int32, P, P, P]),
     "aq3d_spconv_coded_supported": (c_int32, [c_int32, c_int32, c_int32]),
@@ -81,9 +81,6 @@ SIGNATURES = {
     "aq3d_piece_absmax": (c_int32, [P, c_int32, c_int32, c_int32, c_int32, P, P]),
     "aq3d_sq_param_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "aq3d_sq_prep": (c_int32, [P, P, P, POINTER(Conv2dGeom), c_float, c_int32, c_int32, c_float, P, P, P, P]),
-    "aq3d_spconv_workspace_bytes": (c_size_t, [c_int32, c_int32]),
-    "aq3d_spconv_ws": (c_int32, [P, c_int32, P, P, c_int32, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32,
-                                 c_int32, P, P, P, c_size_t, P]),
     "aq3d_spconv_group": (c_int32, [POINTER(SpconvProblem), c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32,
                                     c_int32, P]),
     "aq3d_sq_prep_group": (c_int32, [POINTER(SqPrepProblem), c_int32, c_int32, c_int32, P]),

@@ -165,40 +165,37 @@ def absmax_cols(x, count, amax=None):
     return amax
 
 
-def quantize_rows(x, amax, count, bits=8, per_tensor=False, want_codes=True, want_fq=False, want_split=False):
-    """→ (codes i8 [cap,C] | None, fq f32 [cap,C] | None, dequant f32 [C]) (+ split f16 [cap,2C] when want_split)."""
+def quantize_rows(x, amax, count, bits=8, per_tensor=False, want_codes=True, want_fq=False):
+    """→ (codes i8 [cap,C] | None, fq f32 [cap,C] | None, dequant f32 [C])."""
     L = _lib.load()
     cap, C = x.shape
     codes = torch.empty((cap, C), dtype=torch.int8, device=x.device) if want_codes else None
     fq = torch.empty((cap, C), dtype=f32, device=x.device) if want_fq else None
     dq = torch.empty((C,), dtype=f32, device=x.device)
-    split = torch.empty((cap, 2 * C), dtype=torch.float16, device=x.device) if want_split else None
     check(L.aq3d_quantize_rows(_p(x), _p(amax), _p(count), cap, C, int(bits), int(bool(per_tensor)), _p(codes), _p(fq),
-                               _p(dq), _p(split), _stream()), "aq3d_quantize_rows")
-    if want_split:
-        return codes, fq, dq, split
+                               _p(dq), _stream()), "aq3d_quantize_rows")
     return codes, fq, dq
 
 
-ACT_F32, ACT_I8, ACT_F16SPLIT = 0, 1, 2
-W_F32, W_I8, W_F16 = 0, 1, 2
+ACT_F32, ACT_I8 = 0, 1
+W_F32, W_I8 = 0, 1
 FLAG_RELU = 1
 
 
 def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequant=None, bias=None, post_scale=None,
-           post_shift=None, residual=None, relu=False, absmax_out=None, out=None, workspace=None):
-    """Gather-GEMM sparse conv. feats_in f32|i8 [*, cin]; weight f32|i8 [kvol, cout, cin]; nbr i32 [cap_out, kvol]."""
+           post_shift=None, residual=None, relu=False, absmax_out=None, out=None):
+    """Gather-GEMM sparse conv (fp32 / weight-only layers). feats_in f32|i8 [*, cin]; weight f32|i8 [kvol, cout, cin];
+    nbr i32 [cap_out, kvol]. The w8a8 QConvNd layers take spconv_prep + spconv_coded."""
     L = _lib.load()
     cap_out, kvol = nbr.shape
-    act_mode = {torch.int8: ACT_I8, torch.float16: ACT_F16SPLIT}.get(feats_in.dtype, ACT_F32)
-    w_mode = {torch.int8: W_I8, torch.float16: W_F16}.get(weight.dtype, W_F32)
-    cin = feats_in.shape[1] // 2 if act_mode == ACT_F16SPLIT else feats_in.shape[1]
+    act_mode = ACT_I8 if feats_in.dtype == torch.int8 else ACT_F32
+    w_mode = W_I8 if weight.dtype == torch.int8 else W_F32
+    cin = feats_in.shape[1]
     assert weight.shape == (kvol, cout, cin), (tuple(weight.shape), (kvol, cout, cin))
     y = out if out is not None else torch.empty((cap_out, cout), dtype=f32, device=nbr.device)
-    check(L.aq3d_spconv_ws(_p(feats_in), act_mode, _p(act_dequant), _p(weight), w_mode, _p(w_dequant), _p(bias),
-                           _p(post_scale), _p(post_shift), _p(residual), _p(nbr), _p(count_out), cap_out, int(feats_in.shape[0]),
-                           cin, cout, kvol, FLAG_RELU if relu else 0, _p(y), _p(absmax_out), _p(workspace),
-                           0 if workspace is None else workspace.numel() * workspace.element_size(), _stream()), "aq3d_spconv")
+    check(L.aq3d_spconv(_p(feats_in), act_mode, _p(act_dequant), _p(weight), w_mode, _p(w_dequant), _p(bias),
+                        _p(post_scale), _p(post_shift), _p(residual), _p(nbr), _p(count_out), cap_out, int(feats_in.shape[0]),
+                        cin, cout, kvol, FLAG_RELU if relu else 0, _p(y), _p(absmax_out), _stream()), "aq3d_spconv")
     return y
 
 
@@ -237,11 +234,6 @@ def spconv_coded(codes, wprep, out_mul, nbr, count_out, *, perm=None, bias=None,
                               _p(nbr), _p(perm), _p(count_out), cap_out, cin, cout, kvol, FLAG_RELU if relu else 0, _p(y),
                               _p(absmax_out), _stream()), "aq3d_spconv_coded")
     return y
-
-
-def spconv_workspace(cap_out, cout, device):
-    """Zeroed scratch for spconv(workspace=...): lets the wide kernel split a tile's offsets over two workgroups."""
-    return torch.zeros((_lib.load().aq3d_spconv_workspace_bytes(int(cap_out), int(cout)),), dtype=torch.uint8, device=device)
 
 
 def spconv_problems(recs):

@@ -136,7 +136,7 @@ def test_w150k_int8_teacher_forced(dev, w150k):
 # ------------------------------------------------------------------ configs[1]: one SubM layer, 30 000 active voxels
 @pytest.mark.parametrize("C", [16, 64, 128])
 def test_subm_layer_30k(dev, w150k, C):
-    """aq3d_quantize_rows + aq3d_spconv on the stage-1 site set of W150k vs oracle.sparse (qconv_act + gather_conv)."""
+    """aq3d_spconv_prep + aq3d_spconv_coded on the stage-1 site set of W150k vs oracle.sparse (qconv_act + gather_conv)."""
     from amdq3d import ops
     from oracle import voxel as V
     cfg = w150k["cfg"]
@@ -161,23 +161,17 @@ def test_subm_layer_30k(dev, w150k, C):
     np.testing.assert_array_equal(nbr.cpu().numpy(), nbr_ref)          # gather table bit-exact (same row order on both sides)
     xd = torch.from_numpy(x).to(dev)
     amax = ops.absmax_cols(xd, count)
-    _, _, _, split = ops.quantize_rows(xd, amax, count, want_codes=False, want_split=True)
-    wk = torch.from_numpy(np.ascontiguousarray(codes.reshape(C, 27, C).transpose(1, 0, 2))).to(dev).to(torch.float16)
+    # production path: int8-coded gather, per-channel scale folded into the per-frame weight copy
+    wk8 = torch.from_numpy(np.ascontiguousarray(codes.reshape(C, 27, C).transpose(1, 0, 2)).astype(np.int8)).to(dev)
     wdq = torch.from_numpy((np.float32(1) / wdiv).astype(np.float32)).to(dev)
+    cds, wprep, out_mul = ops.spconv_prep(xd, amax, count, wk8, wdq)
     am_out = torch.zeros(C, device=dev)
-    y = ops.spconv(split, wk, nbr, count, C, w_dequant=wdq, bias=torch.from_numpy(bias).to(dev), relu=True, absmax_out=am_out)
+    y = ops.spconv_coded(cds, wprep, out_mul, nbr, count, bias=torch.from_numpy(bias).to(dev), relu=True, absmax_out=am_out)
     out = y[:m].cpu().numpy()
     err = np.abs(out - ref).max() / max(1.0, float(np.abs(ref).max()))
     print("SubM %d->%d @ %d voxels, %d pairs: max err %.3e of the output scale" % (C, C, m, int((nbr_ref >= 0).sum()), err))
     assert err <= TOL_LAYER
     np.testing.assert_allclose(am_out.cpu().numpy(), np.abs(ref).max(axis=0), rtol=0, atol=TOL_LAYER * max(1.0, float(np.abs(ref).max())))
-    # production path: int8-coded gather, scale folded into the per-frame weight copy
-    wk8 = torch.from_numpy(np.ascontiguousarray(codes.reshape(C, 27, C).transpose(1, 0, 2)).astype(np.int8)).to(dev)
-    cds, wprep, out_mul = ops.spconv_prep(xd, amax, count, wk8, wdq)
-    y2 = ops.spconv_coded(cds, wprep, out_mul, nbr, count, bias=torch.from_numpy(bias).to(dev), relu=True)
-    err2 = np.abs(y2[:m].cpu().numpy() - ref).max() / max(1.0, float(np.abs(ref).max()))
-    print("   coded path: max err %.3e" % err2)
-    assert err2 <= TOL_LAYER
 
 
 # ------------------------------------------------------------------ configs[4]: VoxelNeXt on S40k

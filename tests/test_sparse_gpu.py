@@ -173,12 +173,6 @@ def test_spconv_int8_codes(dev, cin, cout):
     y = ops.spconv(codes, wk_codes, nbr, count, cout, act_dequant=dq, w_dequant=wdq)[:m].cpu().numpy()
     tol = 2e-5 * max(1.0, np.abs(ref).max())
     assert np.abs(y - ref).max() <= tol
-    # production path: activations pre-split into an fp16 (hi, lo) pair by the quantizer, weight codes held as fp16
-    _, _, _, split = ops.quantize_rows(fin, amax, count, bits=8, want_codes=False, want_split=True)
-    hi, lo = split[:m, :cin].float().cpu().numpy(), split[:m, cin:].float().cpu().numpy()
-    assert np.abs(hi + lo / 2048.0 - aq).max() <= 2.0 ** -21 * max(1.0, np.abs(aq).max())
-    y3 = ops.spconv(split, wk_codes.to(torch.float16), nbr, count, cout, w_dequant=wdq)[:m].cpu().numpy()
-    assert np.abs(y3 - ref).max() <= tol
     # fp32 fake-quant operands through the same kernel
     wk_fq = torch.from_numpy(np.ascontiguousarray(wq.reshape(cout, 27, cin).transpose(1, 0, 2))).to(dev)
     y2 = ops.spconv(fq, wk_fq, nbr, count, cout)[:m].cpu().numpy()
@@ -283,5 +277,6 @@ def test_tile_order(dev, m, kvol):
         if pad:
             lv = np.concatenate([lv, np.zeros((pad, kvol), bool)])
         return int(lv.reshape(-1, 128, kvol).any(axis=1).sum())
-    if m >= 5000:
+    assert units(perm) <= units(np.arange(m))
+    if m >= 40000:
         assert units(perm) < 0.8 * units(np.arange(m))
