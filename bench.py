@@ -59,11 +59,17 @@ def build(cfg_path, dev, n_points=N_POINTS, n_voxels=N_VOXELS, seed0=4, static=F
     init_synthetic_weights(model, 4)
     model.eval()
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.voxel_capacity = int(os.environ.get("AQ3D_VOXEL_CAP", "65536"))
     if cfg.MODEL.NAME == "VoxelNeXt":
         quant.dynamic_quant_voxelnext(model, 8, 8, sq=True)
+    elif static:
+        # quant_centerpoint.py:127-129: calibration forwards on the device (collect_stats), then compute_amax; two frames that are
+        # NOT among the benchmark's eight
+        model.to(dev)
+        cal = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_frames=2, n_points=n_points, n_voxels=n_voxels, seed0=1000 + seed0)
+        quant.quant(model, 8, 8, sq=True, alpha=0.5, static=True, test_loader=[cal.collate_batch([cal[i]]) for i in range(2)], n_batches=2)
     else:
         quant.quant(model, 8, 8, sq=True, alpha=0.5, static=False)
-    model.voxel_capacity = int(os.environ.get("AQ3D_VOXEL_CAP", "65536"))
     model.to(dev)
     return cfg, ds, model, state
 
@@ -259,6 +265,8 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="centerpoint", choices=sorted(WORKLOADS))
+    ap.add_argument("--static", action="store_true", help="static PTQ (calibrated amax, quant_centerpoint.py:127-129) instead of the "
+                    "dynamic recipe: the sparse quantisers run in producer epilogues, no per-frame quantiser launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
@@ -279,7 +287,7 @@ def main():
     D.init("nccl")
     lib.load()
     cfg_path, n_points, n_voxels, wl_desc = WORKLOADS[args.workload]
-    cfg, ds, model, state = build(cfg_path, dev, n_points, n_voxels, seed0=rank_seed0(rank))
+    cfg, ds, model, state = build(cfg_path, dev, n_points, n_voxels, seed0=rank_seed0(rank), static=args.static)
 
     # N_FRAMES distinct frames per rank, resident in HBM before the timed region (also kept in pinned host memory for the
     # H2D-inclusive figure)
@@ -386,7 +394,8 @@ def main():
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
-            "config": {"workload": wl_desc, "frames_per_rank": N_FRAMES, "frame_seeds": "4 + 8*rank + i", "points": n_points,
+            "config": {"workload": wl_desc.replace("w8a8 dynamic", "w8a8 static (calibrated amax)") if args.static else wl_desc,
+                       "frames_per_rank": N_FRAMES, "frame_seeds": "4 + 8*rank + i", "points": n_points,
                        "voxels": n_voxels, "parallelism": "replicas(frames)x%d" % world, "world_size_seen_by_rccl": world_seen,
                        "avg_boxes_per_frame": n_det / max(args.steps, 1)},
             "roofline": roof,
@@ -401,6 +410,11 @@ def main():
                                     "what": "same pipeline, every frame's points copied from pinned host memory inside the step (rank 0)"},
             "warmup_breakdown_ms_per_frame": {k: v[1] / n_warm for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
         }
+        if args.static:       # the oracle legs below restate the dynamic recipe
+            out["accuracy"] = out["cpu_baseline"] = None
+            print(json.dumps(out), flush=True)
+            D.shutdown()
+            return
         if world == 1 and not args.no_accuracy:
             try:
                 out["accuracy"] = accuracy_proxy(cfg, ds, state, model, batches, N_FRAMES)

@@ -71,7 +71,6 @@ def main():
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--order", default="random", choices=["random", "morton", "linear"], help="row order of the voxels")
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle on the smallest size")
-    ap.add_argument("--tile-order", action="store_true", help="rows grouped by neighbour pattern (aq3d_tile_order) before the conv")
     args = ap.parse_args()
     from amdq3d import ops
     from oracle import sparse as OS
@@ -100,20 +99,21 @@ def main():
             am_out = torch.zeros(C, device=dev)
             bufs = (torch.zeros((cap, C), dtype=torch.int8, device=dev), torch.empty((27, C, 2, C), dtype=torch.float16, device=dev),
                     torch.empty((C,), device=dev))
-            perm = nbr_t = None
-            if args.tile_order:
-                perm, nbr_t = ops.tile_order(nbr, count)
 
             def prep():
                 ops.spconv_prep(x, amax, count, wk8, wdq, out=bufs)
 
             def conv():
-                return ops.spconv_coded(bufs[0], bufs[1], bufs[2], nbr_t if perm is not None else nbr, count, perm=perm,
-                                        post_scale=ps, post_shift=pt, relu=True, absmax_out=am_out, out=out)
+                return ops.spconv_coded(bufs[0], bufs[1], bufs[2], nbr, count, post_scale=ps, post_shift=pt, relu=True, absmax_out=am_out, out=out)
 
             def timed(fn):
-                for _ in range(5):
-                    fn()
+                # warm up for >= 30 ms: after the host-side set-up of a configuration (seconds of numpy) the GPU sits at idle clocks
+                # and the first launches run several times slower — the 1 922 us outlier of the round-1 sweep was such a reading
+                t0 = time.time()
+                while time.time() - t0 < 0.03:
+                    for _ in range(5):
+                        fn()
+                    torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
                 e0.record()
@@ -130,7 +130,7 @@ def main():
             byts = b_prep + b_conv
             flops = 2.0 * pairs * C * C
             rec = {"layer": "SubMConv3d 3x3x3 %d->%d int8-w x per-channel-quantised a" % (C, C), "occupancy": args.occupancy, "order": args.order,
-                   "tile_order": bool(args.tile_order), "voxels": m, "pairs": pairs, "us_per_layer": us, "us_prep": us_prep, "us_conv": us_conv,
+                   "voxels": m, "pairs": pairs, "us_per_layer": us, "us_prep": us_prep, "us_conv": us_conv,
                    "algorithmic_bytes": byts, "algorithmic_GBps": byts / us / 1e3, "frac_hbm": byts / us / 1e3 / HBM_GBS,
                    "conv_only_GBps": b_conv / us_conv / 1e3, "conv_only_frac_hbm": b_conv / us_conv / 1e3 / HBM_GBS,
                    "useful_TFLOPs": flops / us / 1e6, "frac_mfma_f16": 2 * flops / us_conv / 1e6 / F16_TFLOPS, "voxels_per_s": m / us * 1e6}

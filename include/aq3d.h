@@ -125,13 +125,6 @@ int aq3d_conv_outputs(const int32_t *coords_in, const int32_t *count_in, int32_t
                       int64_t *out_keys, int32_t *out_vals, int32_t out_table_size,
                       void *workspace, size_t workspace_bytes, void *stream);
 
-/* Tile order of a gather table (no reference counterpart: spconv's implicit-GEMM "mask argsort" plays this role inside the
- * library the reference calls at pcdet/models/backbones_3d/spconv_backbone.py:12-17): rows of nbr i32 [*count, kvol] are
- * grouped by their occupancy pattern (sorted per chunk of 16 384 rows). perm_out i32 [cap]: position i of the tile order is
- * output row perm_out[i]; nbr_sorted_out i32 [cap, kvol]: row i = nbr[perm_out[i]]. Consumed by aq3d_spconv_coded(perm). */
-int aq3d_tile_order(const int32_t *nbr, const int32_t *count, int32_t cap, int32_t kvol, int32_t *perm_out,
-                    int32_t *nbr_sorted_out, void *stream);
-
 /* ---------------------------------------------------------------- sparse conv ----------------- */
 
 /* Per-column abs-max of x f32 [*count, C] → amax f32 [C] (amax must be zeroed by the caller). */
@@ -155,7 +148,7 @@ enum {
     AQ3D_W_F32 = 0,    /* weight is f32 [kvol, Cout, Cin]                           */
     AQ3D_W_I8 = 1      /* weight is i8 codes [kvol, Cout, Cin]; value = code * w_dequant[cout] */
 };
-enum { AQ3D_FLAG_RELU = 1 };
+enum { AQ3D_FLAG_RELU = 1, AQ3D_FLAG_SKIP_F32 = 2 /* aq3d_spconv_coded with next_codes: do not store the fp32 rows */ };
 
 /*
  * Output-stationary gather-GEMM sparse convolution with fused epilogue (fp32 layers — conv_input, unquantised models — and
@@ -171,7 +164,10 @@ int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant
                 const float *bias, const float *post_scale, const float *post_shift,
                 const float *residual, const int32_t *nbr, const int32_t *count_out, int32_t cap_out, int32_t cap_in,
                 int32_t cin, int32_t cout, int32_t kvol, int32_t flags,
-                float *feats_out, float *absmax_out, void *stream);
+                float *feats_out, float *absmax_out, const float *next_scale, int8_t *next_codes, int32_t next_bits, void *stream);
+/* next_scale / next_codes (both NULL or both set; aq3d_spconv: stem layer only, cin <= 8): static PTQ — the calibrated quantiser
+ * of the layer that consumes y runs in this epilogue: next_codes i8 [cap_out, Cout] = clamp(rint(y * next_scale[o]), -2^(b-1),
+ * 2^(b-1)-1) in the code layout aq3d_spconv_coded reads, next_scale[o] = (2^(b-1)-1) / amax_o (0 where amax_o <= 2^-24). */
 
 /* One layer of a grouped aq3d_spconv launch (the pointer arguments of aq3d_spconv). */
 typedef struct aq3d_spconv_problem {
@@ -196,8 +192,9 @@ int aq3d_spconv_group(const aq3d_spconv_problem *problems, int32_t n, int32_t ac
  *   (1 byte per element; for C >= 64 the bytes of every 64-channel group are permuted, an internal layout only
  *   aq3d_spconv_coded reads), AND the per-frame weight copy wprep_out (aq3d_spconv_wprep_bytes: W' as fp16 hi | lo planes,
  *   22 significant bits) + out_mul_out f32 [Cout] = S * w_dequant. weight_codes i8 [kvol, Cout, C]; bits <= 8.
- * aq3d_spconv_coded: the gather-GEMM with the epilogue of aq3d_spconv. perm (may be NULL): row i of nbr / of the tile order
- *   is output row perm[i] (tiles of rows with similar neighbour patterns skip kernel offsets none of their rows has). */
+ *   Either half may be skipped: x == NULL builds the weight copy only (static PTQ: once, the scales are constants),
+ *   weight_codes == NULL quantises the rows only.
+ * aq3d_spconv_coded: the gather-GEMM with the epilogue of aq3d_spconv (incl. next_scale / next_codes / AQ3D_FLAG_SKIP_F32). */
 int aq3d_spconv_coded_supported(int32_t cin, int32_t cout, int32_t kvol);
 size_t aq3d_spconv_wprep_bytes(int32_t cin, int32_t cout, int32_t kvol);
 int aq3d_spconv_prep(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C, int32_t bits,
@@ -205,8 +202,9 @@ int aq3d_spconv_prep(const float *x, const float *amax, const int32_t *count, in
                      int8_t *codes_out, void *wprep_out, float *out_mul_out, void *stream);
 int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void *wprep, const float *out_mul, const float *bias,
                       const float *post_scale, const float *post_shift, const float *residual, const int32_t *nbr,
-                      const int32_t *perm, const int32_t *count_out, int32_t cap_out, int32_t cin, int32_t cout, int32_t kvol,
-                      int32_t flags, float *feats_out, float *absmax_out, void *stream);
+                      const int32_t *count_out, int32_t cap_out, int32_t cin, int32_t cout, int32_t kvol,
+                      int32_t flags, float *feats_out, float *absmax_out, const float *next_scale, int8_t *next_codes,
+                      int32_t next_bits, void *stream);
 
 /* ---------------------------------------------------------------- sparse → dense -------------- */
 

@@ -34,7 +34,6 @@ struct ConvArgs {
     int rows_total;         // GEMM rows: Cout (conv) or deconv*deconv*Cout
     float *pieces_out;      // optional [16][pieces_ld] abs-max accumulator of the output image
     int pieces_ld;
-    long long *stamps;      // diagnostic builds only (AQ3D_I8_STAMP)
     int pieces_mode;        // 0: 16 exact classes; 1: the four interior classes merged (all consumers have stride 1)
     int xcd_order;          // int8 generic kernel: pixel tiles dealt to XCDs in contiguous ranges (grid x padded to 8)
 };
@@ -313,370 +312,6 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     }
 }
 
-// ------------------------------------------------------------------ int8 SmoothQuant conv, halo-staged (3x3, stride 1, pad 1)
-// The generic kernel above re-reads every fp32 activation from L2 once per tap and issues the loads of K step s+1 with only
-// the MFMAs of step s as cover, so every one of its 18-36 K steps ends in an exposed L2 round trip (rocprof: 38 % of the
-// wave cycles parked in s_waitcnt, VALU 53 % busy, MFMA 8 %). Here a workgroup owns a TR x 16 pixel tile and works in
-// 32-channel chunks: the fp32 halo ((TR+2) x 18 pixels), the int8 weights of all 9 taps and their scale vectors are
-// fetched into registers ONE CHUNK AHEAD and stored to LDS at the chunk boundary; inside a chunk the 5 K steps (2 taps x 32
-// channels = K 64 of v_mfma_i32_16x16x64_i8) touch only LDS: quantise step s+1 from the halo (VALU) behind the MFMAs of
-// step s, one barrier per step. Arithmetic is identical to the generic kernel (same codes, same int32 sums).
-template <int TI, int TR, bool STAMP>
-__global__ __launch_bounds__(256) void conv2d_i8_halo_kernel(ConvArgs a) {
-    constexpr int BM = 32 * TI;            // output channels per workgroup (2 wave rows x TI x 16)
-    constexpr int BN = TR * 16;            // pixels per workgroup: TR tile rows x 16 columns
-    constexpr int TJ = TR / 2;             // 16-pixel tile rows per wave (2 wave columns)
-    constexpr int LD = 80;                 // bytes per LDS operand row: 64 + 16 pad
-    constexpr int PITCH = 19;              // halo pixels per halo row (18 + 1: the two taps of a step land on different bank halves)
-    constexpr int HPIX = (TR + 2) * 18;    // halo pixels fetched per chunk
-    constexpr int NH = (HPIX * 8 + 255) / 256;   // 16-byte halo items per thread
-    constexpr int NSTEP = 5;               // tap pairs (0,1) (2,3) (4,5) (6,7) (8,-)
-    constexpr int WITEMS = NSTEP * BM * 4; // 16-byte weight pieces per chunk
-    constexpr int WPT = (WITEMS + 255) / 256;
-    __shared__ __attribute__((aligned(16))) float halo[(TR + 2) * PITCH * 32];
-    __shared__ __attribute__((aligned(16))) char wlds[NSTEP * BM * LD];       // [step][oc row][64 B + pad]
-    __shared__ __attribute__((aligned(16))) char xlds[2 * BN * LD];
-    __shared__ __attribute__((aligned(16))) float slds[2 * 10 * 32];          // [s | r][tap 0..9][32 channels] (tap 9 = pad)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave & 1, wn = wave >> 1;
-    const int g = lane >> 4, l15 = lane & 15;
-    const int K = a.Cin * 9;
-    const int tiles_w = (a.W + 15) >> 4;
-    const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
-    const int h0 = th * TR, w0 = tw * 16;
-    const int oc0 = blockIdx.y * BM;
-    const int nchunk = a.Cin >> 5;
-    const float sx = a.scal[0];
-    const bool clamp = a.scal[3] != 0.f;
-
-    // quantisation role: channel quad q, which tap of the pair, pixel column pl; items = the TR tile rows of that column
-    const int q = tid & 7, half = (tid >> 3) & 1, pl = tid >> 4;
-
-    f32x4 hreg[NH];
-    i32x4 wreg[WPT];
-    float sreg[3];
-    auto load_chunk = [&](int chunk) {                 // halo + weights + scales of one 32-channel chunk -> registers
-#pragma unroll
-        for (int i = 0; i < NH; ++i) {
-            const int t = tid + 256 * i;
-            const int hp = t >> 3, hq = t & 7;
-            const int hr = hp / 18, hc = hp - hr * 18;
-            const int h = h0 - 1 + hr, w = w0 - 1 + hc;
-            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (hp < HPIX && h >= 0 && h < a.H && w >= 0 && w < a.W)
-                v = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)h * a.W + w) * a.in_ld + chunk * 32 + hq * 4);
-            hreg[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int item = tid + 256 * i;            // (step, row, 16-byte piece): pieces 0,1 = first tap, 2,3 = second tap
-            const int pc = item & 3, row = (item >> 2) % BM, step = item / (4 * BM);
-            const int wtap = 2 * step + (pc >> 1);
-            const int orow = min(oc0 + row, a.Cout - 1);
-            i32x4 v = (i32x4){0, 0, 0, 0};
-            if (wtap < 9 && (WITEMS % 256 == 0 || item < WITEMS))
-                v = *reinterpret_cast<const i32x4 *>(static_cast<const int8_t *>(a.w) + (size_t)orow * K + (size_t)wtap * a.Cin + chunk * 32 + (pc & 1) * 16);
-            wreg[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {                  // 2 x 10 x 32 scale slots over 256 threads
-            const int j = tid + 256 * i;
-            const int tp = (j % 320) >> 5, c = j & 31;
-            const float *src = j < 320 ? a.s : a.rinv;
-            sreg[i] = (j < 640 && tp < 9) ? src[tp * a.Cin + chunk * 32 + c] : 1.f;
-        }
-    };
-    auto store_chunk = [&]() {
-#pragma unroll
-        for (int i = 0; i < NH; ++i) {
-            const int t = tid + 256 * i;
-            const int hp = t >> 3, hq = t & 7;
-            const int hr = hp / 18, hc = hp - hr * 18;
-            if (hp < HPIX) *reinterpret_cast<f32x4 *>(halo + (hr * PITCH + hc) * 32 + hq * 4) = hreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int item = tid + 256 * i;
-            if (WITEMS % 256 == 0 || item < WITEMS)
-                *reinterpret_cast<i32x4 *>(wlds + (item >> 2) * LD + (item & 3) * 16) = wreg[i];     // row index = step * BM + row
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (tid + 256 * i < 640) slds[tid + 256 * i] = sreg[i];
-    };
-    // halo -> registers (this thread's TR pixels of tap pair `step`), then registers -> int8 codes -> X operand buffer: split so
-    // that the LDS reads of step s+2 are issued a whole step before the VALU that consumes them
-    auto read_halo = [&](f32x4 (&hv)[TR], int step) {
-        const int tap = 2 * step + half;
-        const int tt = tap < 9 ? tap : 0;
-        const float *hp = halo + ((tt / 3) * PITCH + pl + (tt - (tt / 3) * 3)) * 32 + q * 4;
-#pragma unroll
-        for (int i = 0; i < TR; ++i) hv[i] = *reinterpret_cast<const f32x4 *>(hp + i * PITCH * 32);
-    };
-    auto quantize = [&](const f32x4 (&hv)[TR], int step, int buf) {
-        const int tap = 2 * step + half;
-        const float sxv = tap < 9 ? sx : 0.f;           // the pad half of the last pair is all zeros
-        const f32x4 sv = *reinterpret_cast<const f32x4 *>(slds + tap * 32 + q * 4);
-        const f32x4 rv = *reinterpret_cast<const f32x4 *>(slds + 320 + tap * 32 + q * 4);
-        int code[TR];
-        if (clamp) {                                    // block-uniform
-#pragma unroll
-            for (int i = 0; i < TR; ++i) code[i] = quant_pack4<true>(hv[i], sv, rv, sxv);
-        } else {
-#pragma unroll
-            for (int i = 0; i < TR; ++i) code[i] = quant_pack4<false>(hv[i], sv, rv, sxv);
-        }
-#pragma unroll
-        for (int i = 0; i < TR; ++i) *reinterpret_cast<int *>(xlds + buf * BN * LD + (i * 16 + pl) * LD + half * 32 + q * 4) = code[i];
-    };
-
-    i32x4 acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = (i32x4){0, 0, 0, 0};
-    auto read_frags = [&](i32x4 (&af)[TI], i32x4 (&bf)[TJ], int step, int buf) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-            af[i] = *reinterpret_cast<const i32x4 *>(wlds + (step * BM + wm * (BM / 2) + i * 16 + l15) * LD + g * 16);
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-            bf[j] = *reinterpret_cast<const i32x4 *>(xlds + buf * BN * LD + (wn * (BN / 2) + j * 16 + l15) * LD + g * 16);
-    };
-    auto mfma_all = [&](const i32x4 (&af)[TI], const i32x4 (&bf)[TJ]) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-            for (int j = 0; j < TJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
-    };
-
-    long long st[6] = {0, 0, 0, 0, 0, 0};
-    auto now = [&]() -> long long { return STAMP ? (long long)__builtin_amdgcn_s_memtime() : 0; };
-    const long long tk0 = now();
-    load_chunk(0);
-    int buf = 0;
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        long long t0 = now();
-        __syncthreads();                                  // every wave is done with the previous chunk's halo / weights
-        store_chunk();
-        __syncthreads();
-        long long t1 = now();
-        st[0] += t1 - t0;
-        if (chunk + 1 < nchunk) load_chunk(chunk + 1);    // in flight during the 5 LDS-only steps below
-        f32x4 hx[TR], hn[TR];
-        read_halo(hx, 0);
-        quantize(hx, 0, buf);
-        read_halo(hx, 1);
-        long long t2 = now();
-        st[1] += t2 - t1;
-        __syncthreads();
-        st[3] += now() - t2;
-        // per step, in this order: issue the MFMA operand reads of step s, the halo reads of step s+2, then quantise step s+1
-        // (its inputs were read a step ago), then the MFMAs (their operands landed under the VALU work) — one wave alone on
-        // its SIMD no longer pays LDS latency + VALU chain + MFMA back to back
-#pragma unroll
-        for (int step = 0; step < NSTEP; ++step) {
-            long long u0 = now();
-            i32x4 af[TI], bf[TJ];
-            read_frags(af, bf, step, buf);
-            if (step + 2 < NSTEP) read_halo(hn, step + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (step + 1 < NSTEP) quantize(hx, step + 1, buf ^ 1);
-            long long u1 = now();
-            __builtin_amdgcn_sched_barrier(0);
-            mfma_all(af, bf);
-            long long u2 = now();
-            __syncthreads();
-            long long u3 = now();
-            st[1] += u1 - u0; st[2] += u2 - u1; st[3] += u3 - u2;
-            buf ^= 1;
-#pragma unroll
-            for (int i = 0; i < TR; ++i) hx[i] = hn[i];
-        }
-    }
-    if (STAMP && tid == 0) {
-        st[4] = now() - tk0;
-        for (int i = 0; i < 5; ++i) atomicAdd((unsigned long long *)&a.stamps[i], (unsigned long long)st[i]);
-        atomicAdd((unsigned long long *)&a.stamps[5], 1ull);
-    }
-
-    // epilogue: lane holds oc = base + 4g .. 4g+3 for tile pixel (row j of this wave, column l15)
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int oc = oc0 + wm * (BM / 2) + i * 16 + 4 * g;
-        if (oc >= a.Cout) continue;
-        const f32x4 mul = *reinterpret_cast<const f32x4 *>(a.out_mul + oc);
-        f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f}, ps = (f32x4){1.f, 1.f, 1.f, 1.f}, pt = b;
-        if (a.bias) b = *reinterpret_cast<const f32x4 *>(a.bias + oc);
-        if (a.post_scale) {
-            ps = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
-            pt = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
-        }
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int h = h0 + wn * TJ + j, w = w0 + l15;
-            if (h >= a.Ho || w >= a.Wo) continue;
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = __fmul_rn((float)acc[i][j][r], mul[r]);
-                if (a.bias) t = __fadd_rn(t, b[r]);
-                if (a.post_scale) t = __fadd_rn(__fmul_rn(t, ps[r]), pt[r]);
-                if (a.relu) t = fmaxf(t, 0.f);
-                v[r] = t;
-            }
-            *reinterpret_cast<f32x4 *>(a.y + ((size_t)h * a.Wo + w) * a.out_ld + a.out_coff + oc) = v;
-        }
-    }
-}
-
-// ------------------------------------------------------------------ int8 SmoothQuant conv, register-direct (3x3, stride 1, pad 1)
-// No LDS round trip for the activations at all: the B operand of v_mfma_i32_16x16x64_i8 is, per lane, 16 consecutive K
-// bytes of ONE pixel — here 16 channels of one tap — so every lane loads those 16 fp32 values itself (bounded buffer loads,
-// out-of-image taps read zeros), quantises them in registers and feeds the MFMA directly. A wave owns 16 pixels of one
-// image row and ALL output channels of the workgroup, so nothing is quantised twice. Only the int8 weights and the scale
-// vectors go through LDS, one whole 32-channel chunk (9 taps) at a time: the chunk after next is fetched into registers
-// while the 5 K steps of the current one run WITHOUT any barrier (measured on the per-step-staged variants: each K step
-// ended in an exposed ~1 us L2 round trip for 8 KB of weights). K step = 2 taps x 32 channels (lane group g: tap
-// 2p + (g >> 1), channels (g & 1) * 16 ...). The 9 taps of a chunk re-read a 14 KB halo that stays in the CU's L1; the
-// loads of step s+1 are issued before the MFMAs of step s.
-template <int TI>
-__global__ __launch_bounds__(256) void conv2d_i8_direct_kernel(ConvArgs a) {
-    constexpr int BM = 16 * TI;            // output channels per workgroup (every wave computes all of them)
-    constexpr int LD = 80;                 // bytes per LDS weight row: 64 + 16 pad
-    constexpr int NSTEP = 5;               // tap pairs (0,1) (2,3) (4,5) (6,7) (8,-)
-    constexpr int WITEMS = NSTEP * BM * 4; // 16-byte weight pieces per chunk
-    constexpr int WPT = (WITEMS + 255) / 256;
-    __shared__ __attribute__((aligned(16))) char wlds[NSTEP * BM * LD];
-    __shared__ __attribute__((aligned(16))) float slds[2 * 10 * 32];      // [s | r][tap 0..9][32 channels] (tap 9 = pad)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, l15 = lane & 15;
-    const int K = a.Cin * 9;
-    const int tiles_w = (a.W + 15) >> 4;
-    const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
-    const int h = th * 4 + wave, w = tw * 16 + l15;          // this lane's output pixel
-    const int oc0 = blockIdx.y * BM;
-    const int nchunk = a.Cin >> 5;
-    const float sx = a.scal[0];
-    const bool clamp = a.scal[3] != 0.f;
-    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.H * a.W * a.in_ld * 4, 0x00020000);
-    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.Cout * K, 0x00020000);
-
-    i32x4 wreg[WPT];
-    float sreg[3];
-    auto load_w = [&](int chunk) {                    // weights + scales of one 32-channel chunk (all 9 taps); chunk >= nchunk: zeros
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int item = tid + 256 * i;            // (step, row, 16-byte piece): pieces 0,1 = first tap, 2,3 = second tap
-            const int pc = item & 3, row = (item >> 2) % BM, step = item / (4 * BM);
-            const int wtap = 2 * step + (pc >> 1);
-            const int orow = min(oc0 + row, a.Cout - 1);
-            const bool ok = wtap < 9 && chunk < nchunk && (WITEMS % 256 == 0 || item < WITEMS);
-            const unsigned off = ok ? (unsigned)(orow * K + wtap * a.Cin + chunk * 32 + (pc & 1) * 16) : 0xfffffff0u;
-            wreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0));
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {                  // 2 x 10 x 32 scale slots over 256 threads
-            const int j = tid + 256 * i;
-            const int tp = (j % 320) >> 5, c = j & 31;
-            const float *src = j < 320 ? a.s : a.rinv;
-            sreg[i] = (j < 640 && tp < 9 && chunk < nchunk) ? src[tp * a.Cin + chunk * 32 + c] : 1.f;
-        }
-    };
-    auto store_w = [&]() {
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int item = tid + 256 * i;
-            if (WITEMS % 256 == 0 || item < WITEMS)
-                *reinterpret_cast<i32x4 *>(wlds + (item >> 2) * LD + (item & 3) * 16) = wreg[i];     // row index = step * BM + row
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (tid + 256 * i < 640) slds[tid + 256 * i] = sreg[i];
-    };
-    auto load_x = [&](f32x4 (&xr)[4], int chunk, int step) {
-        const int tap = 2 * step + (g >> 1);
-        const int kh = tap / 3, kw = tap - kh * 3;
-        const int hi = h - 1 + kh, wi = w - 1 + kw;
-        const bool ok = tap < 9 && chunk < nchunk && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-        const unsigned off = ok ? (unsigned)(((hi * a.W + wi) * a.in_ld + chunk * 32 + (g & 1) * 16) * 4) : 0xfffffff0u;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off + 16 * i, 0, 0));
-    };
-
-    i32x4 acc[TI];
-#pragma unroll
-    for (int i = 0; i < TI; ++i) acc[i] = (i32x4){0, 0, 0, 0};
-    auto mma_step = [&](int step, const f32x4 (&xv)[4]) {
-        // this lane's 16 channels: scales from LDS (16-lane groups read the same 64 bytes: broadcast, no conflicts)
-        const float *sp = slds + (2 * step + (g >> 1)) * 32 + (g & 1) * 16;
-        i32x4 bfrag;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 sv = *reinterpret_cast<const f32x4 *>(sp + 4 * i);
-            const f32x4 rv = *reinterpret_cast<const f32x4 *>(sp + 320 + 4 * i);
-            bfrag[i] = clamp ? quant_pack4<true>(xv[i], sv, rv, sx) : quant_pack4<false>(xv[i], sv, rv, sx);
-        }
-        const char *wb = wlds + (step * BM + l15) * LD + g * 16;
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const i32x4 af = *reinterpret_cast<const i32x4 *>(wb + i * 16 * LD);
-            acc[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bfrag, acc[i], 0, 0, 0);
-        }
-    };
-
-    // Activations run two K steps ahead (three register sets). vmcnt retires in order, so a load issued behind the weight
-    // prefetch waits for it: the weights of the next chunk are issued after the loads of steps 1 and 2 and are first waited
-    // for (implicitly) at step 3 — three steps of cover instead of none.
-    f32x4 r0[4], r1[4], r2[4];
-    load_w(0);
-    load_x(r0, 0, 0);
-    load_x(r1, 0, 1);
-    for (int chunk = 0; chunk < nchunk; ++chunk) {
-        __syncthreads();                                  // every wave is done with the previous chunk's weights
-        store_w();
-        __syncthreads();
-        load_x(r2, chunk, 2);
-        load_w(chunk + 1);                                // lands under steps 0-2
-        mma_step(0, r0); load_x(r0, chunk, 3);
-        mma_step(1, r1); load_x(r1, chunk, 4);
-        mma_step(2, r2); load_x(r2, chunk + 1, 0);
-        mma_step(3, r0); load_x(r0, chunk + 1, 1);
-        mma_step(4, r1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { r1[i] = r0[i]; r0[i] = r2[i]; }
-    }
-
-    // epilogue: lane holds oc = 16 i + 4g .. 4g+3 of its pixel
-    if (h < a.Ho && w < a.Wo) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int oc = oc0 + i * 16 + 4 * g;
-            if (oc >= a.Cout) continue;
-            const f32x4 mul = *reinterpret_cast<const f32x4 *>(a.out_mul + oc);
-            f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f}, ps = (f32x4){1.f, 1.f, 1.f, 1.f}, pt = b;
-            if (a.bias) b = *reinterpret_cast<const f32x4 *>(a.bias + oc);
-            if (a.post_scale) {
-                ps = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
-                pt = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
-            }
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = __fmul_rn((float)acc[i][r], mul[r]);
-                if (a.bias) t = __fadd_rn(t, b[r]);
-                if (a.post_scale) t = __fadd_rn(__fmul_rn(t, ps[r]), pt[r]);
-                if (a.relu) t = fmaxf(t, 0.f);
-                v[r] = t;
-            }
-            *reinterpret_cast<f32x4 *>(a.y + ((size_t)h * a.Wo + w) * a.out_ld + a.out_coff + oc) = v;
-        }
-    }
-}
-
 // ------------------------------------------------------------------ fp32 conv / transposed conv
 // WM x WN waves; wave tile (TI*16) rows x (TJ*16) pixels; K step = KS input channels of one tap (KS = 32 halves the
 // barriers but measured no faster than 16, which is what is launched).
@@ -862,7 +497,6 @@ static int fill_args(ConvArgs *a, const float *x, const aq3d_conv2d_geom *g, con
     a->s = a->rinv = a->scal = a->out_mul = nullptr;
     a->pieces_out = nullptr;
     a->pieces_ld = 0;
-    a->stamps = nullptr;
     a->pieces_mode = 0;
     a->xcd_order = 0;
     a->w = nullptr;
@@ -908,7 +542,6 @@ extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n,
     AQ3D_REQUIRE(probs && n >= 1 && n <= AQ3D_MAX_GROUP, "aq3d_conv2d_i8_group: n=%d not in 1..%d", n, AQ3D_MAX_GROUP);
     ConvGroup grp;
     int max_cout = 0;
-    bool any_pieces = false;
     for (int i = 0; i < n; ++i) {
         AQ3D_REQUIRE(probs[i].geom, "aq3d_conv2d_i8_group: null geometry");
         int rc = prep_i8(&grp.p[i], &probs[i]);
@@ -916,73 +549,28 @@ extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n,
         AQ3D_REQUIRE(same_class(probs[0].geom, probs[i].geom) && (probs[0].geom->Cout >= 128) == (probs[i].geom->Cout >= 128),
                      "aq3d_conv2d_i8_group: problem %d is not of the launch class of problem 0", i);
         max_cout = probs[i].geom->Cout > max_cout ? probs[i].geom->Cout : max_cout;
-        any_pieces |= probs[i].pieces_out != nullptr;
     }
     for (int i = n; i < AQ3D_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     const aq3d_conv2d_geom *g = probs[0].geom;
-    ConvArgs &a = grp.p[0];
-    const float *pieces_out = any_pieces ? (const float *)1 : nullptr;
     const int L = g->Ho * g->Wo;
-    static const bool no_halo = getenv("AQ3D_I8_HALO") == nullptr;      // experiment, off by default: not faster than the generic kernel
-    static const bool no_direct = getenv("AQ3D_I8_DIRECT") == nullptr;      // measured slower: per-lane 16-byte loads of 64-byte pixel pieces thrash the TA
-    if (n == 1 && !no_direct && !pieces_out && g->ksize == 3 && g->stride == 1 && g->pad == 1 && (g->Cin & 31) == 0 &&
-        (int64_t)g->H * g->W * g->in_ld * 4 < (int64_t)0xfffffff0) {
-        const int bm = g->Cout >= 128 ? 128 : 64;
-        const dim3 grid(aq3d_div_up(g->H, 4) * aq3d_div_up(g->W, 16), aq3d_div_up(g->Cout, bm));
-        if (bm == 128) hipLaunchKernelGGL((conv2d_i8_direct_kernel<8>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv2d_i8_direct_kernel<4>), grid, dim3(256), 0, stream, a);
-        AQ3D_CHECK_LAUNCH("aq3d_conv2d_i8(direct)");
-        return AQ3D_OK;
-    }
-    if (n == 1 && !no_halo && !pieces_out && g->ksize == 3 && g->stride == 1 && g->pad == 1 && (g->Cin & 31) == 0) {
-        // halo-staged kernel; tile rows chosen so that there are >= 2 workgroups per CU where the image allows it
-        const int bm = g->Cout >= 128 ? 128 : 64;
-        const int ocb2 = aq3d_div_up(g->Cout, bm), tw = aq3d_div_up(g->W, 16);
-        const int tr = (aq3d_div_up(g->H, 8) * tw * ocb2 >= 512) ? 8 : 4;
-        const dim3 grid(aq3d_div_up(g->H, tr) * tw, ocb2);
-        static const bool stamp = getenv("AQ3D_I8_STAMP") != nullptr;
-        if (stamp && bm == 128 && tr == 4) {     // diagnostic path: blocking, prints the phase cycle averages of this launch
-            static long long *dev = nullptr;
-            if (!dev) (void)hipMalloc((void **)&dev, 64);
-            (void)hipMemsetAsync(dev, 0, 64, stream);
-            a.stamps = dev;
-            hipLaunchKernelGGL((conv2d_i8_halo_kernel<4, 4, true>), grid, dim3(256), 0, stream, a);
-            long long hst[8];
-            (void)hipStreamSynchronize(stream);
-            (void)hipMemcpy(hst, dev, 64, hipMemcpyDeviceToHost);
-            const double nn = (double)(hst[5] ? hst[5] : 1);
-            fprintf(stderr, "[i8 halo %dx%d C%d->%d] per wg cycles: chunk-swap %.0f  quantize %.0f  mma %.0f  barrier %.0f  | loop total %.0f\n",
-                    g->H, g->W, g->Cin, g->Cout, hst[0] / nn, hst[1] / nn, hst[2] / nn, hst[3] / nn, hst[4] / nn);
-            return AQ3D_OK;
-        }
-        if (bm == 128 && tr == 8) hipLaunchKernelGGL((conv2d_i8_halo_kernel<4, 8, false>), grid, dim3(256), 0, stream, a);
-        else if (bm == 128) hipLaunchKernelGGL((conv2d_i8_halo_kernel<4, 4, false>), grid, dim3(256), 0, stream, a);
-        else if (tr == 8) hipLaunchKernelGGL((conv2d_i8_halo_kernel<2, 8, false>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((conv2d_i8_halo_kernel<2, 4, false>), grid, dim3(256), 0, stream, a);
-        AQ3D_CHECK_LAUNCH("aq3d_conv2d_i8(halo)");
-        return AQ3D_OK;
-    }
     // pixel-tile width: enough workgroups for >= 2 per CU (the K loop is a latency chain, it needs co-resident partners)
-    static const int force_bn = getenv("AQ3D_I8_BN") ? atoi(getenv("AQ3D_I8_BN")) : 0;
     const int ocb = max_cout >= 128 ? aq3d_div_up(max_cout, 128) : aq3d_div_up(max_cout, 64);
     int bn = 128;
     if (aq3d_div_up(L, 128) * ocb * n < 512) bn = 64;
     if (aq3d_div_up(L, 64) * ocb * n < 512) bn = 32;
-    if (force_bn) bn = force_bn;
-    static const int nwn_env = getenv("AQ3D_I8_WAVES") ? atoi(getenv("AQ3D_I8_WAVES")) / 2 : 0;
-    const int nwn = nwn_env == 2 || nwn_env == 4 ? nwn_env : 2;      // 8 waves (AQ3D_I8_WAVES=8) measured equal to 4: the VALU op count is what binds
-    static const bool xcd = !(getenv("AQ3D_I8_XCD") && atoi(getenv("AQ3D_I8_XCD")) == 0);
-    for (int i = 0; i < AQ3D_MAX_GROUP; ++i) grp.p[i].xcd_order = xcd ? 1 : 0;
-#define AQ3D_I8_LAUNCH(TI_, TJ_, NWN_) \
-    hipLaunchKernelGGL((conv2d_i8_kernel<TI_, TJ_, NWN_>), dim3(xcd ? aq3d_div_up(aq3d_div_up(L, 16 * TJ_ * NWN_), 8) * 8 : aq3d_div_up(L, 16 * TJ_ * NWN_), ocb, n), dim3(128 * NWN_), 0, stream, grp)
+    // pixel tiles are dealt to the 8 XCDs in contiguous ranges (grid x padded to a multiple of 8): vertically adjacent tiles of a
+    // 3x3 conv re-read each other's input rows and then share an L2
+    for (int i = 0; i < AQ3D_MAX_GROUP; ++i) grp.p[i].xcd_order = 1;
+#define AQ3D_I8_LAUNCH(TI_, TJ_) \
+    hipLaunchKernelGGL((conv2d_i8_kernel<TI_, TJ_, 2>), dim3(aq3d_div_up(aq3d_div_up(L, 32 * TJ_), 8) * 8, ocb, n), dim3(256), 0, stream, grp)
     if (g->Cout >= 128) {
-        if (bn == 128) { if (nwn == 4) AQ3D_I8_LAUNCH(4, 2, 4); else AQ3D_I8_LAUNCH(4, 4, 2); }
-        else if (bn == 64) { if (nwn == 4) AQ3D_I8_LAUNCH(4, 1, 4); else AQ3D_I8_LAUNCH(4, 2, 2); }
-        else AQ3D_I8_LAUNCH(4, 1, 2);
+        if (bn == 128) AQ3D_I8_LAUNCH(4, 4);
+        else if (bn == 64) AQ3D_I8_LAUNCH(4, 2);
+        else AQ3D_I8_LAUNCH(4, 1);
     } else {
-        if (bn == 128) { if (nwn == 4) AQ3D_I8_LAUNCH(2, 2, 4); else AQ3D_I8_LAUNCH(2, 4, 2); }
-        else if (bn == 64) { if (nwn == 4) AQ3D_I8_LAUNCH(2, 1, 4); else AQ3D_I8_LAUNCH(2, 2, 2); }
-        else AQ3D_I8_LAUNCH(2, 1, 2);
+        if (bn == 128) AQ3D_I8_LAUNCH(2, 4);
+        else if (bn == 64) AQ3D_I8_LAUNCH(2, 2);
+        else AQ3D_I8_LAUNCH(2, 1);
     }
 #undef AQ3D_I8_LAUNCH
     AQ3D_CHECK_LAUNCH("aq3d_conv2d_i8");
@@ -1007,7 +595,7 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
 // differs from exact fp32 products by ~5e-7 relative, below the reordering noise of any fp32 GEMM (and far below the TF32 the
 // reference's cuDNN uses for these convolutions on Ampere). 3 MFMAs of 16 cycles per 32-deep K step instead of 8 of 32 cycles:
 // the fp32 matrix pipe (157 TFLOP/s) was what bound the deblocks. |x| must stay below the fp16 range (65504); the exact
-// fp32-pipe kernel above remains available through AQ3D_F32_EXACT=1.
+// fp32-pipe kernel above takes the layers whose Cin is not a multiple of 32.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int WM, int WN, int TI, int TJ, int KS>
@@ -1236,19 +824,13 @@ extern "C" int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *probs, int32_t n
         max_rows = grp.p[i].rows_total > max_rows ? grp.p[i].rows_total : max_rows;
     }
     for (int i = n; i < AQ3D_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
-    static const bool exact = getenv("AQ3D_F32_EXACT") && atoi(getenv("AQ3D_F32_EXACT")) != 0;
-    bool split_ok = !exact;
+    bool split_ok = true;
     for (int i = 0; i < n; ++i) split_ok = split_ok && (probs[i].geom->Cin & 31) == 0;
     if (split_ok) {     // fp16 matrix pipe, split operands (see conv2d_f16s_kernel)
-        static const int ks64 = getenv("AQ3D_F16S_KS64") ? atoi(getenv("AQ3D_F16S_KS64")) : 0;
-        bool k64 = ks64 != 0;
-        for (int i = 0; i < n; ++i) k64 = k64 && (probs[i].geom->Cin & 63) == 0;
         if (cls == 0) {
-            if (k64) hipLaunchKernelGGL((conv2d_f16s_kernel<1, 4, 1, 2, 64>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
-            else hipLaunchKernelGGL((conv2d_f16s_kernel<1, 4, 1, 2, 32>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
-        } else {        // 64 x 64 tiles for both deblock shapes (128-row tiles measured slower: conversion work, 63 KB of LDS)
-            if (k64) hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 64>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
-            else hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 32>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
+            hipLaunchKernelGGL((conv2d_f16s_kernel<1, 4, 1, 2, 32>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
+        } else {        // 64 x 64 tiles for both deblock shapes (128-row tiles measured slower: conversion work, 63 KB of LDS; 64-deep K steps: no gain)
+            hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 32>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
         }
         AQ3D_CHECK_LAUNCH("aq3d_conv2d_f32");
         return AQ3D_OK;

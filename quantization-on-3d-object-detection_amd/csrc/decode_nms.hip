@@ -410,7 +410,7 @@ extern "C" int aq3d_center_decode(const float *hm, const float *center, const fl
     const int Kpad = next_pow2(K);
     u64 *cand = (u64 *)workspace;
     size_t lds1 = (size_t)Kpad * 8 + 256 * 4 + 16 * 4;
-    static const bool no_filter = getenv("AQ3D_TOPK_NOFILTER") != nullptr;
+    const bool no_filter = false;     // the order-preserving score-threshold pre-filter is always on (identical detections)
     // key cache [L] — or, in the pre-filtered mode, keys + pixel indices of up to 16384 candidates (2 x 64 KiB)
     const size_t key_bytes = (size_t)L * 4 > 131072 ? (size_t)L * 4 : 131072;
     const int cache_keys = (lds1 + key_bytes <= 150 * 1024) ? 1 : 0;   // one workgroup may use up to 160 KiB of LDS

@@ -371,10 +371,10 @@ extern "C" int aq3d_sq_prep_group(const aq3d_sq_prep_problem *probs, int32_t n, 
     for (int i = n; i < AQ3D_SQ_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     const int ntaps = g->ksize * g->ksize, K = g->Cin * ntaps;
     const float qa = (float)((1 << (a_bits - 1)) - 1), qw = (float)((1 << (w_bits - 1)) - 1);
-    // AQ3D_SQ_PREP_FUSED=0 selects the two-kernel path (scales, then one block per output channel)
-    static const bool fused = !(getenv("AQ3D_SQ_PREP_FUSED") && atoi(getenv("AQ3D_SQ_PREP_FUSED")) == 0);
+    // one launch (scales and codes from registers, piece maxima through LDS) when a weight row fits the block; otherwise two
+    // kernels (scales, then one block per output channel)
     const size_t lds_bytes = 16 * (size_t)g->Cin * 4;
-    if (fused && (g->Cin & 3) == 0 && K <= 4 * SQ_V * SQ_FUSED_THREADS && lds_bytes <= 60 * 1024) {
+    if ((g->Cin & 3) == 0 && K <= 4 * SQ_V * SQ_FUSED_THREADS && lds_bytes <= 60 * 1024) {
         hipLaunchKernelGGL(sq_prep_row_kernel, dim3(max_cout, n), dim3(SQ_FUSED_THREADS), lds_bytes, stream, grp, g->Cin, ntaps, tm,
                            qw, qa);
         AQ3D_CHECK_LAUNCH("aq3d_sq_prep");

@@ -34,6 +34,10 @@ struct SpconvArgs {
     float *feats_out;
     float *absmax_out;
     int cap_out, cin, kvol, relu;
+    // static PTQ (stem kernel only): the consumer's calibrated quantiser in this epilogue — codes i8 [cap_out][cout <= 32]
+    const float *next_scale;
+    int8_t *next_codes;
+    float next_qmax;
 };
 
 // up to 8 independent layers of one shape in a single grid (blockIdx.y = problem): the VoxelNeXt head runs 72 small
@@ -478,6 +482,11 @@ __global__ __launch_bounds__(256) void spconv_stem_kernel(SpconvArgs a, int cout
             if (a.residual) v = __fadd_rn(v, a.residual[(size_t)row * cout + o]);
             if (a.relu) v = fmaxf(v, 0.f);
             a.feats_out[(size_t)row * cout + o] = v;
+            if (a.next_codes) {       // cout < 64: identity code layout
+                float q = rintf(__fmul_rn(v, a.next_scale[o]));
+                q = fminf(fmaxf(q, -a.next_qmax - 1.f), a.next_qmax);
+                a.next_codes[(size_t)row * cout + o] = (int8_t)(int)q;
+            }
             mx[j] = fabsf(v);
         }
     }
@@ -496,15 +505,22 @@ __global__ __launch_bounds__(256) void spconv_stem_kernel(SpconvArgs a, int cout
     }
 }
 
-extern "C" int aq3d_spconv_group(const aq3d_spconv_problem *probs, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
-                                 int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, void *stream_);
+static int spconv_group_impl(const aq3d_spconv_problem *probs, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
+                             int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, const float *next_scale,
+                             int8_t *next_codes, float next_qmax, void *stream_);
 
 extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant, const void *weight,
                            int32_t w_mode, const float *w_dequant, const float *bias, const float *post_scale,
                            const float *post_shift, const float *residual, const int32_t *nbr,
                            const int32_t *count_out, int32_t cap_out, int32_t cap_in, int32_t cin, int32_t cout,
-                           int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, void *stream_) {
+                           int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, const float *next_scale,
+                           int8_t *next_codes, int32_t next_bits, void *stream_) {
     AQ3D_REQUIRE(feats_in && weight && nbr && count_out && feats_out, "aq3d_spconv: null argument");
+    AQ3D_REQUIRE((next_scale == nullptr) == (next_codes == nullptr), "aq3d_spconv: next_scale / next_codes must come together");
+    if (next_codes) {       // only the stem kernel carries the consumer's static quantiser
+        AQ3D_REQUIRE(act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && cin <= 8 && (cout & 3) == 0 && cout <= 32 && next_bits >= 2 && next_bits <= 8,
+                     "aq3d_spconv: next_codes is supported by the stem layer only (fp32, cin <= 8, cout <= 32)");
+    }
     AQ3D_REQUIRE(cap_out > 0 && kvol >= 1 && kvol <= 27, "aq3d_spconv: cap_out=%d kvol=%d", cap_out, kvol);
     AQ3D_REQUIRE(cin >= 1 && cin <= 128, "aq3d_spconv: cin=%d not in 1..128", cin);
     AQ3D_REQUIRE(act_mode != AQ3D_ACT_I8 || ((cin % 16) == 0 && act_dequant), "aq3d_spconv: int8 activations need cin%%16==0 and act_dequant");
@@ -514,11 +530,18 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
     q.feats_in = feats_in; q.act_dequant = act_dequant; q.weight = weight; q.w_dequant = w_dequant; q.bias = bias;
     q.post_scale = post_scale; q.post_shift = post_shift; q.residual = residual; q.nbr = nbr; q.count_out = count_out;
     q.feats_out = feats_out; q.absmax_out = absmax_out;
-    return aq3d_spconv_group(&q, 1, act_mode, w_mode, cap_out, cap_in, cin, cout, kvol, flags, stream_);
+    return spconv_group_impl(&q, 1, act_mode, w_mode, cap_out, cap_in, cin, cout, kvol, flags, next_scale, next_codes,
+                             next_codes ? (float)((1 << (next_bits - 1)) - 1) : 0.f, stream_);
 }
 
 extern "C" int aq3d_spconv_group(const aq3d_spconv_problem *probs, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
                                  int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, void *stream_) {
+    return spconv_group_impl(probs, n, act_mode, w_mode, cap_out, cap_in, cin, cout, kvol, flags, nullptr, nullptr, 0.f, stream_);
+}
+
+static int spconv_group_impl(const aq3d_spconv_problem *probs, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
+                             int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, const float *next_scale,
+                             int8_t *next_codes, float next_qmax, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     (void)cap_in;
     AQ3D_REQUIRE(probs && n >= 1 && n <= AQ3D_SPCONV_MAX_GROUP, "aq3d_spconv_group: n=%d not in 1..%d", n, AQ3D_SPCONV_MAX_GROUP);
@@ -536,6 +559,7 @@ extern "C" int aq3d_spconv_group(const aq3d_spconv_problem *probs, int32_t n, in
         a.bias = q.bias; a.post_scale = q.post_scale; a.post_shift = q.post_shift; a.residual = q.residual;
         a.nbr = q.nbr; a.count_out = q.count_out; a.feats_out = q.feats_out; a.absmax_out = q.absmax_out;
         a.cap_out = cap_out; a.cin = cin; a.kvol = kvol; a.relu = (flags & AQ3D_FLAG_RELU) ? 1 : 0;
+        a.next_scale = next_scale; a.next_codes = next_codes; a.next_qmax = next_qmax;
     }
     for (int i = n; i < AQ3D_SPCONV_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     const SpconvArgs &a = grp.p[0];

@@ -148,13 +148,24 @@ struct SpCodedArgs {
     const _Float16 *wp;       // [kvol][COUT][2][CIN]
     const float *out_mul;     // [COUT]
     const float *bias, *post_scale, *post_shift, *residual;
-    const int *nbr;           // [cap_out][kvol]   (rows in TILE order when perm != nullptr)
-    const int *perm;          // [cap_out] tile order -> output row, or nullptr (identity)
+    const int *nbr;           // [cap_out][kvol]
     const int *count_out;
     float *feats_out, *absmax_out;
     int cap_out, kvol, relu;
     unsigned codes_bytes;
+    // static PTQ: the consumer's quantiser runs in this epilogue (its calibrated scale is a constant): codes of the output rows
+    const float *next_scale;  // [COUT] qmax / amax_c of the consumer (0 for a dead channel), or nullptr
+    int8_t *next_codes;       // [cap_out][COUT] in the consumer's code layout
+    float next_qmax;
+    int skip_f32;             // nobody reads the fp32 rows (no residual / feature-map use): do not store them
 };
+
+// TensorQuantizer with a calibrated amax: clamp(rint(v * scale), -qmax - 1, qmax) — the arithmetic of sp_prep_kernel
+__device__ __forceinline__ signed char cd_static_code(float v, float scale, float qmax) {
+    float q = rintf(__fmul_rn(v, scale));
+    q = fminf(fmaxf(q, -qmax - 1.f), qmax);
+    return (signed char)(int)q;
+}
 
 // Cin = 16: K chunk = 2 kernel offsets x 16 channels; lane (l15, g) holds 8 channels of offset 2q + (g >> 1).
 template <int COUT, int KVOL, int NW>
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int trow = tile * TMW + wave * 16 + l15;                // position in tile order
+        const int trow = tile * TMW + wave * 16 + l15;
         int nb[KVOL];
 #pragma unroll
         for (int k = 0; k < KVOL; ++k) {
@@ -211,8 +222,8 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
             const int idx = (g >> 1) ? i1 : i0;
             const unsigned off = idx >= 0 ? (unsigned)(idx * CIN + (g & 1) * 8) : CD_OOB;
             const i32x2v cv = __builtin_amdgcn_raw_buffer_load_b64(rsrc_f, off, 0, 0);   // no neighbour: out of range, no traffic
-            // none of the wave's 16 rows has a neighbour at these two offsets (the common case once the rows are in tile
-            // order): skip the conversion, the LDS reads and the MFMAs — adding exact zeros changes nothing
+            // none of the wave's 16 rows has a neighbour at these two offsets: skip the conversion, the LDS reads and the
+            // MFMAs — adding exact zeros changes nothing
             if (__builtin_amdgcn_ballot_w64(idx >= 0) != 0ull) {
                 const f16x8 fa = cd_cvt8(cv.x, cv.y);
 #pragma unroll
@@ -233,18 +244,21 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
             const float b = a.bias ? a.bias[o] : 0.f;
             const float ps = a.post_scale ? a.post_scale[o] : 1.f;
             const float pt = a.post_shift ? a.post_shift[o] : 0.f;
+            const float nsc = a.next_codes ? a.next_scale[o] : 0.f;
+            const int npos = cd_code_pos(o, COUT);
             float mx = 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int tr = tile * TMW + wave * 16 + 4 * g + r;
                 if (tr < n) {
-                    const int m = a.perm ? a.perm[tr] : tr;
+                    const int m = tr;
                     float v = __fmul_rn(acc[nt][r], mul);
                     if (a.bias) v = __fadd_rn(v, b);
                     if (a.post_scale) v = __fadd_rn(__fmul_rn(v, ps), pt);
                     if (a.residual) v = __fadd_rn(v, a.residual[(size_t)m * COUT + o]);
                     if (a.relu) v = fmaxf(v, 0.f);
-                    a.feats_out[(size_t)m * COUT + o] = v;
+                    if (!a.skip_f32) a.feats_out[(size_t)m * COUT + o] = v;
+                    if (a.next_codes) a.next_codes[(size_t)m * COUT + npos] = cd_static_code(v, nsc, a.next_qmax);
                     mx = fmaxf(mx, fabsf(v));
                 }
             }
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int tr = row0 + wave * (RT * 16) + rt * 16 + 4 * g + r;
-            mrow[rt][r] = tr < n ? (a.perm ? a.perm[tr] : tr) : -1;
+            mrow[rt][r] = tr < n ? tr : -1;
         }
     float cmax[NT];
 #pragma unroll
@@ -455,6 +469,8 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
         const float bs = a.bias ? a.bias[o] : 0.f;
         const float ps = a.post_scale ? a.post_scale[o] : 1.f;
         const float pt = a.post_shift ? a.post_shift[o] : 0.f;
+        const float nsc = a.next_codes ? a.next_scale[o] : 0.f;
+        const int npos = cd_code_pos(o, COUT);
         float mx = 0.f;
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -467,7 +483,8 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
                     if (a.post_scale) v = __fadd_rn(__fmul_rn(v, ps), pt);
                     if (a.residual) v = __fadd_rn(v, a.residual[(size_t)m * COUT + o]);
                     if (a.relu) v = fmaxf(v, 0.f);
-                    a.feats_out[(size_t)m * COUT + o] = v;
+                    if (!a.skip_f32) a.feats_out[(size_t)m * COUT + o] = v;
+                    if (a.next_codes) a.next_codes[(size_t)m * COUT + npos] = cd_static_code(v, nsc, a.next_qmax);
                     mx = fmaxf(mx, fabsf(v));
                 }
             }
@@ -528,7 +545,10 @@ extern "C" int aq3d_spconv_prep(const float *x, const float *amax, const int32_t
                                 int32_t per_tensor, const int8_t *weight_codes, const float *w_dequant, int32_t kvol,
                                 int32_t cout, int8_t *codes_out, void *wprep_out, float *out_mul_out, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    AQ3D_REQUIRE(x && amax && count && weight_codes && w_dequant && codes_out && wprep_out && out_mul_out, "aq3d_spconv_prep: null argument");
+    const bool rows = x != nullptr, weights = weight_codes != nullptr;
+    AQ3D_REQUIRE(amax && (rows || weights), "aq3d_spconv_prep: null argument");
+    AQ3D_REQUIRE(!rows || (count && codes_out), "aq3d_spconv_prep: the row quantiser needs count and codes_out");
+    AQ3D_REQUIRE(!weights || (w_dequant && wprep_out && out_mul_out), "aq3d_spconv_prep: the weight copy needs w_dequant, wprep_out and out_mul_out");
     AQ3D_REQUIRE(C >= 16 && C <= 256 && (C & 15) == 0 && bits >= 2 && bits <= 8, "aq3d_spconv_prep: C=%d bits=%d", C, bits);
     AQ3D_REQUIRE(cap > 0 && kvol >= 1 && kvol <= 27 && cout >= 1, "aq3d_spconv_prep: cap=%d kvol=%d cout=%d", cap, kvol, cout);
     AQ3D_REQUIRE((long long)cap * C < (1ll << 31), "aq3d_spconv_prep: cap * C overflows 32-bit indexing");
@@ -536,8 +556,8 @@ extern "C" int aq3d_spconv_prep(const float *x, const float *amax, const int32_t
     a.x = x; a.amax = amax; a.count = count; a.cap = cap; a.C = C; a.qmax = (float)((1 << (bits - 1)) - 1);
     a.per_tensor = per_tensor; a.codes = codes_out; a.w = weight_codes; a.w_dequant = w_dequant; a.wp = (_Float16 *)wprep_out;
     a.out_mul = out_mul_out; a.kvol = kvol; a.cout = cout;
-    a.row_blocks = aq3d_grid((int64_t)cap * C / 4, 256);
-    const int wblocks = aq3d_grid((int64_t)kvol * cout * C / 8, 256, 256);
+    a.row_blocks = rows ? aq3d_grid((int64_t)cap * C / 4, 256) : 0;
+    const int wblocks = weights ? aq3d_grid((int64_t)kvol * cout * C / 8, 256, 256) : 0;
     hipLaunchKernelGGL(sp_prep_kernel, dim3(a.row_blocks + wblocks), dim3(256), 0, stream, a);
     AQ3D_CHECK_LAUNCH("aq3d_spconv_prep");
     return AQ3D_OK;
@@ -545,8 +565,9 @@ extern "C" int aq3d_spconv_prep(const float *x, const float *amax, const int32_t
 
 extern "C" int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void *wprep, const float *out_mul, const float *bias,
                                  const float *post_scale, const float *post_shift, const float *residual, const int32_t *nbr,
-                                 const int32_t *perm, const int32_t *count_out, int32_t cap_out, int32_t cin, int32_t cout,
-                                 int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, void *stream_) {
+                                 const int32_t *count_out, int32_t cap_out, int32_t cin, int32_t cout,
+                                 int32_t kvol, int32_t flags, float *feats_out, float *absmax_out, const float *next_scale,
+                                 int8_t *next_codes, int32_t next_bits, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AQ3D_REQUIRE(codes && wprep && out_mul && nbr && count_out && feats_out, "aq3d_spconv_coded: null argument");
     AQ3D_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "aq3d_spconv_coded: post_scale/post_shift must come together");
@@ -557,10 +578,15 @@ extern "C" int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void
     }
     SpCodedArgs a;
     a.codes = codes; a.wp = (const _Float16 *)wprep; a.out_mul = out_mul; a.bias = bias; a.post_scale = post_scale;
-    a.post_shift = post_shift; a.residual = residual; a.nbr = nbr; a.perm = perm; a.count_out = count_out;
+    a.post_shift = post_shift; a.residual = residual; a.nbr = nbr; a.count_out = count_out;
     a.feats_out = feats_out; a.absmax_out = absmax_out; a.cap_out = cap_out; a.kvol = kvol;
     a.relu = (flags & AQ3D_FLAG_RELU) ? 1 : 0;
     a.codes_bytes = (unsigned)((int64_t)cap_in * cin);
+    AQ3D_REQUIRE((next_scale == nullptr) == (next_codes == nullptr), "aq3d_spconv_coded: next_scale / next_codes must come together");
+    AQ3D_REQUIRE(!next_codes || (next_bits >= 2 && next_bits <= 8), "aq3d_spconv_coded: next_bits=%d", next_bits);
+    AQ3D_REQUIRE(!(flags & AQ3D_FLAG_SKIP_F32) || next_codes, "aq3d_spconv_coded: AQ3D_FLAG_SKIP_F32 without next_codes would discard the output");
+    a.next_scale = next_scale; a.next_codes = next_codes; a.next_qmax = next_codes ? (float)((1 << (next_bits - 1)) - 1) : 0.f;
+    a.skip_f32 = (flags & AQ3D_FLAG_SKIP_F32) ? 1 : 0;
     if (cin == 16 && cout == 16) return launch_cd<16, 27, 4>(a, stream);
     if (cin == 16 && cout == 32) return launch_cd<32, 27, 8>(a, stream);    // 58 KB of W' per workgroup: 8 waves share it
     if (cin == 32 && cout == 32) return launch_cw<32, 32>(a, stream);

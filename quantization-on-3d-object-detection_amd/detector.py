@@ -39,7 +39,9 @@ class Detector3DTemplate(nn.Module):
         self._main_stream = None
         self._ev_prev_main = None
         self._rr = 0
-        self.async_streams = int(os.environ.get("AQ3D_STREAMS", "1"))   # device plans of forward_async for un-split plans (VoxelNeXt: 1 plan 213, 2 plans 267 frames/s — but see DESIGN.md §9: not yet bit-reproducible with 2); split plans use max(4, this)
+        # device plans of forward_async for un-split plans (VoxelNeXt): 1 plan 212, 2 plans 262 frames/s; bit-reproducible since the
+        # library is built without packed-fp32 instructions. Split plans (CenterPoint) use max(4, this).
+        self.async_streams = int(os.environ.get("AQ3D_STREAMS", "2"))
         self.max_batch_size = 1          # engine buffers are sized for this many frames per forward
         self.voxel_capacity = None       # rows of the sparse buffers (default MAX_NUMBER_OF_VOXELS * max_batch_size)
         self.voxelize_on_device = True   # False: consume batch_dict['voxels'/'voxel_coords'] when present
@@ -212,8 +214,6 @@ class Detector3DTemplate(nn.Module):
         overlap as well (see forward_async). One frame per plan is in flight at any time."""
         primary = self.engine()
         n = max(1, int(self.async_streams)) if not primary.split_index else max(4, int(self.async_streams))
-        if os.environ.get("AQ3D_SPLIT_INDEX", "1") == "0":
-            n = max(1, int(self.async_streams))
         if os.environ.get("AQ3D_ASYNC_ENGINES"):
             n = max(1, int(os.environ["AQ3D_ASYNC_ENGINES"]))
         while len(self._extra_engines) < n - 1:

@@ -132,14 +132,11 @@ class Engine:
         self.max_voxels = int(vcfg.MAX_NUMBER_OF_VOXELS["test"])
         cap_opt = getattr(det, "voxel_capacity", None)
         self.cap = int(cap_opt) if cap_opt else self.max_voxels * self.batch_cap
-        # rows of the gather tables grouped by neighbour pattern so that 128-row tiles skip kernel offsets (csrc/tile_order.hip):
-        # "0" off, "1" every table read by a coded conv, "auto" only the tables of 128-output-channel 3x3x3 convs (the layers
-        # bound by the matrix pipe; the LDS sort costs ~0.36 ms per table on the index stream)
-        self.tile_order = os.environ.get("AQ3D_TILE_ORDER", "0")
         self.arena = _Arena(device)
         self.steps = []
         self.tensors = {}
         self._voxel_ws = None
+        self._force_rows = False     # teacher-forced tests: run the rows-only quantiser even where a producer epilogue does it
         if isinstance(det.backbone_3d, VoxelResBackBone8xVoxelNeXt):
             self.fully_sparse = True
             self._build_voxelnext(det.backbone_3d, det.dense_head)
@@ -150,7 +147,7 @@ class Engine:
         self.arena.finalize()
         # split plan: the index chain (incl. the voxelizer) is a phase of its own that forward_async runs a frame ahead on a
         # second stream; VoxelNeXt's bev_merge makes later index steps depend on features, so its plan stays in one piece
-        self.split_index = (not self.fully_sparse) and os.environ.get("AQ3D_SPLIT_INDEX", "1") != "0"
+        self.split_index = not self.fully_sparse
         self.index_steps = [st for st in self.steps if st[0] in self.INDEX_KINDS] if self.split_index else []
         self.main_steps = [st for st in self.steps if st[0] not in self.INDEX_KINDS] if self.split_index else list(self.steps)
         self._graph_now = self._warm_now = False
@@ -187,7 +184,7 @@ class Engine:
         dev, cap = self.device, self.cap
         lv = dict(shape=list(shape), coords=torch.zeros((cap, 4), dtype=i32, device=dev),
                   count=torch.zeros((1,), dtype=i32, device=dev), table=ops.HashTable(cap, dev),
-                  nbr=torch.full((cap, kvol), -1, dtype=i32, device=dev), subm_ksize=(3, 3, 3), tiled=None)
+                  nbr=torch.full((cap, kvol), -1, dtype=i32, device=dev), subm_ksize=(3, 3, 3))
         self.levels.append(lv)
         return lv
 
@@ -251,8 +248,6 @@ class Engine:
             coded = q.act_bits <= 8 and rec["w_dequant"] is not None and ops.spconv_coded_supported(cin, cout, kvol)
             rec["coded"] = rec["quant"]["use_codes"] = coded
             if coded:
-                if self.tile_order == "1" or (self.tile_order == "auto" and cout == 128 and kvol == 27):
-                    self._request_tile_order(nbr)
                 rec["codes"] = torch.zeros((cap, cin), dtype=torch.int8, device=dev)
                 # W' = code * (d_c / S) as fp16 hi | lo planes + epilogue multipliers S * t_o, rebuilt per frame by aq3d_spconv_prep
                 rec["wprep"] = torch.zeros((kvol, cout, 2, cin), dtype=torch.float16, device=dev)
@@ -321,6 +316,7 @@ class Engine:
         x = self._compile_spconv(co[0], "backbone_3d.conv_out.0", x, 4, ("down", 4), kvol, co[1], True)
         self.encoded = (x, 4)
         self._alloc_index_ws()
+        self._plan_static_sparse()
 
     def _alloc_index_ws(self):
         L = ops._lib.load()
@@ -433,6 +429,7 @@ class Engine:
         self.dense_convs = []
         self._group_sparse_head(self.head_first_step)
         self.steps.append(("voxel_decode_nms", None))
+        self._plan_static_sparse()
 
     # ------------------------------------------------------------------ dense BEV backbone + head
     def _build_dense(self, b2d, head):
@@ -445,10 +442,10 @@ class Engine:
         self.dense_convs = []
         self._pieces = {}
         self._producers = {}
-        # piece maxima of a conv's input produced in the epilogue of the conv(s) that wrote it: "1" (default) = int8 producers
-        # feeding stride-1 consumers (register-reduced interior maximum, pieces_mode 1); "all" = every producer, exact 16
-        # classes (per-element LDS atomics: measured slower than the standalone pass); "0" = always the standalone pass
-        self.fuse_pieces = os.environ.get("AQ3D_FUSE_PIECES", "1")
+        # piece maxima of a conv's input come out of the epilogue of the conv(s) that wrote it where that is cheap: int8 producers
+        # feeding stride-1 consumers (register-reduced interior maximum, pieces_mode 1) and the fp32 deblocks (exact 16 classes merged
+        # per workgroup in LDS); every other input gets the standalone aq3d_piece_absmax pass (per-element LDS atomics in the int8
+        # epilogue measured slower than that pass)
         self._pieces_mode = {}
 
         def compile_conv2d(mod, path, x, xH, xW, x_ld, pad_extra, bn, relu, out=None, out_ld=None, out_coff=0):
@@ -494,16 +491,12 @@ class Engine:
                         prods = self._producers.get(x.data_ptr(), [])
                         covered = sum(p_["geom"].Cout for p_ in prods)
                         fusable = prods and covered >= cin and x_ld == cin and xH >= 3 and xW >= 3 and len(pkey) == 5
-                        if fusable and self.fuse_pieces == "all":
-                            for p_ in prods:
-                                p_["pieces_out"] = (self._pieces[pkey], cin, 0)
-                            rec["pieces_owner"] = False
-                        elif fusable and self.fuse_pieces == "1" and s == 1 and all(p_["kind"] == "i8" for p_ in prods):
+                        if fusable and s == 1 and all(p_["kind"] == "i8" for p_ in prods):
                             for p_ in prods:
                                 p_["pieces_out"] = (self._pieces[pkey], cin, 1)
                             self._pieces_mode[pkey] = 1
                             rec["pieces_owner"] = False
-                        elif fusable and self.fuse_pieces == "1" and all(p_["kind"] != "i8" for p_ in prods):
+                        elif fusable and all(p_["kind"] != "i8" for p_ in prods):
                             for p_ in prods:        # fp32 producers (deblocks → bev_cat): exact classes, merged per workgroup in LDS
                                 p_["pieces_out"] = (self._pieces[pkey], cin, 0)
                             rec["pieces_owner"] = False
@@ -846,29 +839,51 @@ class Engine:
             return self.levels[ref[1]]["down"]["nbr"]
         return self.levels[ref]["nbr"]
 
-    def _tile_of(self, ref, level=None):
-        """(gather table in tile order, perm) of a table reference when its rows have been grouped by neighbour pattern
-        (aq3d_tile_order, index phase), else (table, None)."""
-        holder = None
-        if isinstance(ref, tuple):
-            if ref[0] == "down":
-                holder = self.levels[ref[1]]["down"]
-        else:
-            holder = self.levels[ref]
-        t = holder.get("tiled") if holder is not None else None
-        if t is None:
-            return self._nbr_of(ref, level), None
-        return t["nbr"], t["perm"]
-
-    def _request_tile_order(self, ref):
-        """Compile time: the coded convs that read this table want it in tile order (buffers + an index-phase step)."""
-        holder = self.levels[ref[1]]["down"] if isinstance(ref, tuple) else self.levels[ref]
-        if isinstance(ref, tuple) and ref[0] != "down":
+    def _plan_static_sparse(self):
+        """Static PTQ (quant_centerpoint.py:127-129: calibrated amax) for the coded sparse layers: their quantiser scales are
+        constants, so (i) the weight copy W' is built ONCE, here, instead of per frame, (ii) the quantiser of a layer runs in the
+        epilogue of the conv that produces its input (next_scale / next_codes of aq3d_spconv_coded and of the stem layer) — the
+        20 quantiser launches of a frame disappear — and (iii) fp32 rows nobody else reads (the conv1 output of a residual
+        block) are not stored at all. Layers whose producer cannot carry the hook keep a rows-only quantiser launch."""
+        recs = self.sparse_convs
+        static = [r for r in recs if r.get("coded") and r["quant"]["on"] and r["quant"]["static_amax"] is not None]
+        if not static:
             return
-        if holder.get("tiled") is None:
-            nbr = holder["nbr"]
-            holder["tiled"] = dict(nbr=torch.full(tuple(nbr.shape), -1, dtype=i32, device=self.device),
-                                   perm=torch.zeros((self.cap,), dtype=i32, device=self.device))
+        keep_f32 = bool(getattr(self.det, "static_keep_f32", False))
+        by_out = {id(r["out"]): r for r in recs}
+        users = {}
+        for r in recs:
+            users.setdefault(id(r["x"]), []).append(r)
+            if r["residual"] is not None:
+                users.setdefault(id(r["residual"]), []).append(r)
+        pinned = {id(t) for t, _ in self.multi_scale.values()} | {id(self.encoded[0])}
+        if getattr(self, "merge", None):
+            pinned |= {id(x) for x, _, _ in self.merge["srcs"]}
+        eps = np.float32(1.0 / (1 << 24))
+        for r in static:
+            q = r["quant"]
+            amax = _np(q["static_amax"]).reshape(-1).astype(np.float32)
+            if q["per_tensor"] or amax.size == 1:
+                amax = np.full((r["cin"],), amax.max(), np.float32)
+            qmax = np.float32((1 << (q["bits"] - 1)) - 1)
+            with np.errstate(divide="ignore"):
+                scale = np.where(amax <= eps, np.float32(0), qmax / amax).astype(np.float32)
+            r["static"] = dict(amax=self._dev(amax), scale=self._dev(scale), fused=False)
+            # (i) weight copy once
+            ops.spconv_prep(None, r["static"]["amax"], None, r["weight_i8"], r["w_dequant"], bits=q["bits"], per_tensor=False,
+                            out=(None, r["wprep"], r["out_mul"]))
+            # (ii) quantiser into the producer's epilogue
+            p = by_out.get(id(r["x"]))
+            if p is None or "next" in p:
+                continue
+            stem = p["quant"] is None and p["w_dequant"] is None and p["cin"] <= 8 and p["cout"] % 4 == 0 and p["cout"] <= 32
+            if not (p.get("coded") or stem) or p["cout"] != r["cin"]:
+                continue
+            p["next"] = dict(scale=r["static"]["scale"], codes=r["codes"], bits=q["bits"])
+            r["static"]["fused"] = True
+            # (iii) nobody but this quantiser reads the producer's fp32 rows
+            others = [u for u in users.get(id(p["out"]), []) if u is not r]
+            p["skip_f32"] = bool(p.get("coded")) and not others and id(p["out"]) not in pinned and not keep_f32
 
     def _run_spconv(self, rec):
         lv = self.levels[rec["level"]]
@@ -885,16 +900,24 @@ class Engine:
             if q["static_amax"] is not None and q["static_amax"].numel() == 1 and x["C"] > 1:
                 amax = q["static_amax"].expand(x["C"]).contiguous()
             if rec.get("coded"):
-                with _Timed(self, "quantize_rows"):      # quantiser + per-frame weight copy, one launch
-                    ops.spconv_prep(x["buf"], amax, in_count, rec["weight_i8"], rec["w_dequant"], bits=q["bits"],
-                                    per_tensor=q["per_tensor"], out=(rec["codes"], rec["wprep"], rec["out_mul"]))
+                st = rec.get("static")
+                if st is None:
+                    with _Timed(self, "quantize_rows"):      # quantiser + per-frame weight copy, one launch
+                        ops.spconv_prep(x["buf"], amax, in_count, rec["weight_i8"], rec["w_dequant"], bits=q["bits"],
+                                        per_tensor=q["per_tensor"], out=(rec["codes"], rec["wprep"], rec["out_mul"]))
+                elif not st["fused"] or self._force_rows:
+                    with _Timed(self, "quantize_rows"):      # static, producer without the hook: rows only (W' is constant)
+                        ops.spconv_prep(x["buf"], st["amax"], in_count, None, None, bits=q["bits"], per_tensor=False,
+                                        out=(rec["codes"], None, None))
                 out = rec["out"]
-                nbr_t, perm = self._tile_of(rec["nbr"], rec["level"])
+                nx = rec.get("next")
                 with _Timed(self, "spconv_c%d" % rec["cout"]):
-                    ops.spconv_coded(rec["codes"], rec["wprep"], rec["out_mul"], nbr_t, lv["count"], perm=perm, bias=rec["bias"],
+                    ops.spconv_coded(rec["codes"], rec["wprep"], rec["out_mul"], nbr, lv["count"], bias=rec["bias"],
                                      post_scale=rec["post_scale"], post_shift=rec["post_shift"],
                                      residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
-                                     absmax_out=self.arena.view(out["amax"]), out=out["buf"])
+                                     absmax_out=self.arena.view(out["amax"]), out=out["buf"],
+                                     next_scale=None if nx is None else nx["scale"], next_codes=None if nx is None else nx["codes"],
+                                     next_bits=8 if nx is None else nx["bits"], skip_f32=bool(rec.get("skip_f32")))
                 return
             L = ops._lib.load()
             with _Timed(self, "quantize_rows"):
@@ -903,11 +926,14 @@ class Engine:
                           "aq3d_quantize_rows")
             feats = rec["fq"]
         out = rec["out"]
+        nx = rec.get("next")
         with _Timed(self, "spconv_c%d" % rec["cout"]):
             ops.spconv(feats, rec["weight"], nbr, lv["count"], rec["cout"], act_dequant=act_dq, w_dequant=rec["w_dequant"],
                        bias=rec["bias"], post_scale=rec["post_scale"], post_shift=rec["post_shift"],
                        residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
-                       absmax_out=self.arena.view(out["amax"]), out=out["buf"])
+                       absmax_out=self.arena.view(out["amax"]), out=out["buf"],
+                       next_scale=None if nx is None else nx["scale"], next_codes=None if nx is None else nx["codes"],
+                       next_bits=8 if nx is None else nx["bits"])
 
     def _run_conv2d(self, rec, B):
         g = rec["geom"]
@@ -1179,14 +1205,9 @@ class Engine:
                 if "down" not in lv:   # level 0: table from the voxel coords; deeper levels get it from conv_outputs
                     ops.hash_build(lv["coords"], lv["count"], lv["shape"], lv["table"])
                 ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], lv["subm_ksize"], lv["table"], out=lv["nbr"])
-                if lv.get("tiled") is not None:
-                    ops.tile_order(lv["nbr"], lv["count"], out=(lv["tiled"]["perm"], lv["tiled"]["nbr"]))
         elif kind == "index_down":
             with _Timed(self, "rulebook"):
                 self._index_down(arg)
-                d = self.levels[arg]["down"]
-                if d.get("tiled") is not None:
-                    ops.tile_order(d["nbr"], self.levels[arg]["count"], out=(d["tiled"]["perm"], d["tiled"]["nbr"]))
         elif kind == "index_head":
             lv = self.levels[arg]
             with _Timed(self, "rulebook"):

@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class Aq3dError(RuntimeError):
@@ -68,15 +68,15 @@ SIGNATURES = {
     "aq3d_conv_outputs_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "aq3d_conv_outputs": (c_int32, [P, P, c_int32, I3, I3, I3, I3, P, P, c_int32, P, P, c_int32, P, P, P, c_int32,
                                     P, c_size_t, P]),
-    "aq3d_tile_order": (c_int32, [P, P, c_int32, c_int32, P, P, P]),
     "aq3d_absmax_cols": (c_int32, [P, P, c_int32, c_int32, P, P]),
     "aq3d_quantize_rows": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
     "aq3d_spconv": (c_int32, [P, c_int32, P, P, c_int32, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32,
-                              c_int32, P, P, P]),
+                              c_int32, P, P, P, P, c_int32, P]),
     "aq3d_spconv_coded_supported": (c_int32, [c_int32, c_int32, c_int32]),
     "aq3d_spconv_wprep_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "aq3d_spconv_prep": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, P, P, c_int32, c_int32, P, P, P, P]),
-    "aq3d_spconv_coded": (c_int32, [P, c_int32, P, P, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P]),
+    "aq3d_spconv_coded": (c_int32, [P, c_int32, P, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, P,
+                                    c_int32, P]),
     "aq3d_scatter_dense": (c_int32, [P, P, P, c_int32, c_int32, I3, c_int32, P, P]),
     "aq3d_piece_absmax": (c_int32, [P, c_int32, c_int32, c_int32, c_int32, P, P]),
     "aq3d_sq_param_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

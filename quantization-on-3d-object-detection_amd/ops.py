@@ -118,19 +118,6 @@ def subm_neighbors(coords, count, shape, ksize, table, out=None):
     return nbr
 
 
-def tile_order(nbr, count, out=None):
-    """Rows of a gather table grouped by neighbour pattern → (perm i32 [cap], nbr_sorted i32 [cap, kvol]); see aq3d_tile_order."""
-    L = _lib.load()
-    cap, kvol = nbr.shape
-    if out is None:
-        perm = torch.zeros((cap,), dtype=i32, device=nbr.device)
-        nbr_t = torch.full((cap, kvol), -1, dtype=i32, device=nbr.device)
-    else:
-        perm, nbr_t = out
-    check(L.aq3d_tile_order(_p(nbr), _p(count), cap, kvol, _p(perm), _p(nbr_t), _stream()), "aq3d_tile_order")
-    return perm, nbr_t
-
-
 def conv_out_shape(shape, ksize, stride, pad):
     return [(shape[i] + 2 * pad[i] - ksize[i]) // stride[i] + 1 for i in range(3)]
 
@@ -179,11 +166,11 @@ def quantize_rows(x, amax, count, bits=8, per_tensor=False, want_codes=True, wan
 
 ACT_F32, ACT_I8 = 0, 1
 W_F32, W_I8 = 0, 1
-FLAG_RELU = 1
+FLAG_RELU, FLAG_SKIP_F32 = 1, 2
 
 
 def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequant=None, bias=None, post_scale=None,
-           post_shift=None, residual=None, relu=False, absmax_out=None, out=None):
+           post_shift=None, residual=None, relu=False, absmax_out=None, out=None, next_scale=None, next_codes=None, next_bits=8):
     """Gather-GEMM sparse conv (fp32 / weight-only layers). feats_in f32|i8 [*, cin]; weight f32|i8 [kvol, cout, cin];
     nbr i32 [cap_out, kvol]. The w8a8 QConvNd layers take spconv_prep + spconv_coded."""
     L = _lib.load()
@@ -195,7 +182,8 @@ def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequan
     y = out if out is not None else torch.empty((cap_out, cout), dtype=f32, device=nbr.device)
     check(L.aq3d_spconv(_p(feats_in), act_mode, _p(act_dequant), _p(weight), w_mode, _p(w_dequant), _p(bias),
                         _p(post_scale), _p(post_shift), _p(residual), _p(nbr), _p(count_out), cap_out, int(feats_in.shape[0]),
-                        cin, cout, kvol, FLAG_RELU if relu else 0, _p(y), _p(absmax_out), _stream()), "aq3d_spconv")
+                        cin, cout, kvol, FLAG_RELU if relu else 0, _p(y), _p(absmax_out), _p(next_scale), _p(next_codes),
+                        int(next_bits), _stream()), "aq3d_spconv")
     return y
 
 
@@ -203,26 +191,34 @@ def spconv_coded_supported(cin, cout, kvol):
     return bool(_lib.load().aq3d_spconv_coded_supported(int(cin), int(cout), int(kvol)))
 
 
-def spconv_prep(x, amax, count, weight_codes, w_dequant, bits=8, per_tensor=False, out=None):
+def spconv_prep(x, amax, count, weight_codes, w_dequant, bits=8, per_tensor=False, out=None, cap=None):
     """Quantiser + per-frame weight copy of one QConvNd layer in ONE launch (aq3d_spconv_prep).
-    x f32 [cap, C]; weight_codes i8 [kvol, cout, C] → (codes i8 [cap, C], wprep f16 [kvol, cout, 2, C], out_mul f32 [cout])."""
+    x f32 [cap, C]; weight_codes i8 [kvol, cout, C] → (codes i8 [cap, C], wprep f16 [kvol, cout, 2, C], out_mul f32 [cout]).
+    x=None: weight copy only (static PTQ, once); weight_codes=None: rows only."""
     L = _lib.load()
-    cap, C = x.shape
-    kvol, cout, cin = weight_codes.shape
-    assert cin == C and weight_codes.dtype == torch.int8
     if out is None:
-        codes = torch.zeros((cap, C), dtype=torch.int8, device=x.device)
+        cap_, C = x.shape
+        kvol, cout, _ = weight_codes.shape
+        codes = torch.zeros((cap_, C), dtype=torch.int8, device=x.device)
         wprep = torch.empty((kvol, cout, 2, C), dtype=torch.float16, device=x.device)
         out_mul = torch.empty((cout,), dtype=f32, device=x.device)
     else:
         codes, wprep, out_mul = out
-    check(L.aq3d_spconv_prep(_p(x), _p(amax), _p(count), cap, C, int(bits), int(bool(per_tensor)), _p(weight_codes),
-                             _p(w_dequant), kvol, cout, _p(codes), _p(wprep), _p(out_mul), _stream()), "aq3d_spconv_prep")
+    C = int(amax.shape[0])
+    if weight_codes is not None:
+        kvol, cout, cin = weight_codes.shape
+        assert cin == C and weight_codes.dtype == torch.int8
+    else:
+        kvol, cout = 1, 1
+    cap_ = int(x.shape[0]) if x is not None else int(cap or 1)
+    check(L.aq3d_spconv_prep(_p(x), _p(amax), _p(count), cap_, C, int(bits), int(bool(per_tensor)), _p(weight_codes),
+                             _p(w_dequant), kvol, cout, _p(codes) if x is not None else None, _p(wprep) if weight_codes is not None else None,
+                             _p(out_mul) if weight_codes is not None else None, _stream()), "aq3d_spconv_prep")
     return codes, wprep, out_mul
 
 
-def spconv_coded(codes, wprep, out_mul, nbr, count_out, *, perm=None, bias=None, post_scale=None, post_shift=None,
-                 residual=None, relu=False, absmax_out=None, out=None):
+def spconv_coded(codes, wprep, out_mul, nbr, count_out, *, bias=None, post_scale=None, post_shift=None,
+                 residual=None, relu=False, absmax_out=None, out=None, next_scale=None, next_codes=None, next_bits=8, skip_f32=False):
     """Gather-GEMM on int8-coded activations (aq3d_spconv_coded). codes i8 [cap_in, cin]; wprep f16 [kvol, cout, 2, cin]."""
     L = _lib.load()
     cap_out, kvol = nbr.shape
@@ -231,8 +227,9 @@ def spconv_coded(codes, wprep, out_mul, nbr, count_out, *, perm=None, bias=None,
     assert tuple(wprep.shape) == (kvol, cout, 2, cin), (tuple(wprep.shape), (kvol, cout, 2, cin))
     y = out if out is not None else torch.empty((cap_out, cout), dtype=f32, device=nbr.device)
     check(L.aq3d_spconv_coded(_p(codes), cap_in, _p(wprep), _p(out_mul), _p(bias), _p(post_scale), _p(post_shift), _p(residual),
-                              _p(nbr), _p(perm), _p(count_out), cap_out, cin, cout, kvol, FLAG_RELU if relu else 0, _p(y),
-                              _p(absmax_out), _stream()), "aq3d_spconv_coded")
+                              _p(nbr), _p(count_out), cap_out, cin, cout, kvol,
+                              (FLAG_RELU if relu else 0) | (FLAG_SKIP_F32 if skip_f32 else 0), _p(y), _p(absmax_out),
+                              _p(next_scale), _p(next_codes), int(next_bits), _stream()), "aq3d_spconv_coded")
     return y
 
 

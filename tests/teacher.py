@@ -40,6 +40,7 @@ def sparse_layers(eng, maps, oracle_rows, steps=None):
     from amdq3d import ops
     dev = eng.device
     res = []
+    eng._force_rows = True        # static plans: the forced input has to be quantised here, not by a producer epilogue
 
     def put(t):
         rows = oracle_rows(t["name"])
@@ -81,6 +82,7 @@ def sparse_layers(eng, maps, oracle_rows, steps=None):
             for r in arg["recs"]:
                 check(r)
     torch.cuda.synchronize()
+    eng._force_rows = False
     return res
 
 

@@ -34,7 +34,7 @@ def test_argument_validation_returns_codes_not_exit():
     """Unlike the reference's CHECK_* macros (iou3d_nms.cpp:14-26) bad arguments come back as status + message."""
     from amdq3d import lib
     L = lib.load()
-    rc = L.aq3d_spconv(None, 0, None, None, 0, None, None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, None, None, None)
+    rc = L.aq3d_spconv(None, 0, None, None, 0, None, None, None, None, None, None, None, 0, 0, 0, 0, 0, 0, None, None, None, None, 8, None)
     assert rc == -1 and b"null" in L.aq3d_last_error_string()
     with pytest.raises(lib.Aq3dError):
         lib.check(rc, "aq3d_spconv")

@@ -93,6 +93,7 @@ def test_static_ptq_parity_with_the_oracle(dev, shrink):
             np.testing.assert_allclose(m._weight_quantizer.amax.numpy(), d["w"], rtol=2e-5, atol=1e-7, err_msg=path)
     if shrink != 1.0:
         static = {p: {k: np.asarray(v, np.float32) * np.float32(shrink) for k, v in d.items()} for p, d in static.items()}
+    model.static_keep_f32 = True                           # teacher forcing reads every layer's fp32 output
     _set_static(model, static, Qz)                         # identical amax on both sides: codes must agree bit for bit
     batch = ds.collate_batch([ds[0]]); load_data_to_gpu(batch, dev)
     with torch.no_grad():
@@ -111,3 +112,46 @@ def test_static_ptq_parity_with_the_oracle(dev, shrink):
     teacher.report("static PTQ (amax x %.1f), teacher-forced layers; %d first-layer inputs beyond the calibrated range" % (shrink, clipped), res)
     bad = [(p, e) for p, k, e, _ in res if not e <= 2e-5]
     assert not bad, bad
+
+
+def test_static_fast_path_equals_the_launch_per_quantiser_plan(dev):
+    """Static PTQ fast path: consumer quantisers in producer epilogues, the weight copy built once, fp32 rows
+    nobody reads skipped — against the same calibrated model with every quantiser as its own launch on stored fp32 rows:
+    identical codes for every coded layer, identical detections; and the per-frame quantiser launches are gone."""
+    from amdq3d import quant as Qz
+    from amdq3d.datasets import load_data_to_gpu
+    cfg = small_cfg("waymo")
+    ds, model = build_model(cfg, n_points=7000, n_voxels=2000, n_frames=3)
+    model.cuda()
+    loader = [ds.collate_batch([ds[i]]) for i in (1, 2)]
+    Qz.quant(model, 8, 8, sq=True, alpha=0.5, static=True, test_loader=loader, n_batches=5)
+
+    def run(force_rows):
+        eng = model.engine()
+        eng._force_rows = force_rows
+        eng.use_graph = False
+        batch = ds.collate_batch([ds[0]]); load_data_to_gpu(batch, dev)
+        eng.start_timing(["quantize_rows"])
+        with torch.no_grad():
+            pred, _ = model(batch)
+        n_q = eng.stop_timing().get("quantize_rows", (0, 0.0))[0]
+        codes = {}
+        for r in eng.sparse_convs:
+            if r.get("coded"):
+                m = int(eng.levels[r["x"]["level"]]["count"].item())
+                codes[r["path"]] = r["codes"][:m].clone()
+        return eng, pred[0], codes, n_q
+
+    eng, pred_fast, codes_fast, nq_fast = run(False)
+    fused = [r["path"] for r in eng.sparse_convs if r.get("static") and r["static"]["fused"]]
+    skipped = [r["path"] for r in eng.sparse_convs if r.get("skip_f32")]
+    assert len(fused) == 20 and len(skipped) == 8, (len(fused), skipped)      # every coded layer; the conv1 of the 8 residual blocks
+    assert nq_fast == 0
+    model.static_keep_f32 = True
+    model.invalidate_engine()
+    eng2, pred_ref, codes_ref, nq_ref = run(True)
+    assert nq_ref == 20 and not any(r.get("skip_f32") for r in eng2.sparse_convs)
+    for path in codes_ref:
+        assert torch.equal(codes_fast[path], codes_ref[path]), path
+    for k in ("pred_boxes", "pred_scores", "pred_labels"):
+        assert torch.equal(pred_fast[k], pred_ref[k]), k
