@@ -299,6 +299,17 @@ int aq3d_conv2d_f32(const float *x, const float *weight, const aq3d_conv2d_geom 
                     const float *bias, const float *post_scale, const float *post_shift,
                     float *y, float *pieces_out, int32_t pieces_ld, void *stream);
 
+/* SQConv2d.forward (quant/smoothquant.py:38-99) with MORE than 8 activation bits — the reference's "16-bit activation
+ * preservation" (README.md:10,21; act_bits of quant/quant_centerpoint.py:74-83, 257-258). params: the block aq3d_sq_prep wrote
+ * with the same a_bits (smoothing scales, activation scale, int8 weight codes). The codes do not fit the int8 matrix pipe, so
+ * the layer multiplies the fake-quantised VALUES like the reference does: x' = clamp(rint((x / s) * sx)) / sx per (pixel,
+ * tap, channel) while staging, weights = the int8 codes, the per-channel weight step in the epilogue; fp32 accumulation on the
+ * fp16 pipe with split operands. workspace: aq3d_conv2d_sq16_workspace_bytes. */
+size_t aq3d_conv2d_sq16_workspace_bytes(int32_t Cin, int32_t Cout, int32_t ksize);
+int aq3d_conv2d_sq16(const float *x, const void *params, const aq3d_conv2d_geom *g, int32_t w_bits, int32_t a_bits,
+                     const float *bias, const float *post_scale, const float *post_shift, float *y, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------- head decode + NMS ----------- */
 
 typedef struct {

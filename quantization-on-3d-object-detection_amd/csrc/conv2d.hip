@@ -598,7 +598,12 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
 // fp32-pipe kernel above takes the layers whose Cin is not a multiple of 32.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-template <int WM, int WN, int TI, int TJ, int KS>
+// SQ = true: SQConv2d with more than 8 activation bits (the reference's "16-bit activation preservation", README.md:10,21,
+// act_bits of quant_centerpoint.py:74-83). The codes no longer fit the int8 pipe, so the layer runs on fake-quantised VALUES,
+// exactly what the reference multiplies: x' = clamp(rint((x / s) * sx)) / sx per (pixel, tap, channel) while the tile is
+// staged (exact quotients by Markstein correction), weights = the int8 codes of aq3d_sq_prep as fp32 (exact in the hi half),
+// per-channel weight step applied in the epilogue (a.out_mul).
+template <int WM, int WN, int TI, int TJ, int KS, bool SQ = false>
 __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
     const ConvArgs a = grp.p[blockIdx.z];
     if ((int)blockIdx.y * WM * TI * 16 >= a.rows_total) return;
@@ -638,9 +643,15 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
         }
     }
     f32x4 xr[XI], wr[WI];
+    f32x4 sqs = (f32x4){1.f, 1.f, 1.f, 1.f}, sqr = sqs;       // SQ: smoothing scale and its reciprocal of this thread's 4 columns
+    const float sq_sx = SQ ? a.scal[0] : 0.f, sq_rsx = SQ ? a.scal[2] : 0.f, sq_qmax = SQ ? a.scal[4] : 0.f;
     auto load_step = [&](int kstep) {
         const int tap = kstep / cchunks, c0 = (kstep - tap * cchunks) * KS;
         const int kh = tap / a.ks, kw = tap - kh * a.ks;
+        if (SQ) {       // 256 % QPR == 0: the column quad of a thread is the same for all its items
+            sqs = *reinterpret_cast<const f32x4 *>(a.s + (size_t)tap * a.Cin + c0 + (tid % QPR) * 4);
+            sqr = *reinterpret_cast<const f32x4 *>(a.rinv + (size_t)tap * a.Cin + c0 + (tid % QPR) * 4);
+        }
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const int item = tid + 256 * i;
@@ -672,6 +683,16 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
         *reinterpret_cast<f16x4 *>(row + KS + q * 4) = l;
     };
     auto store_step = [&](int buf) {
+        if (SQ) {       // TensorQuantizer on X / s: q = clamp(rint(t * sx), -qmax - 1, qmax), value q / sx (sx = 0 / divide by 1 when amax <= 2^-24)
+#pragma unroll
+            for (int i = 0; i < XI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float q = rintf(__fmul_rn(div_by_scale(xr[i][r], sqs[r], sqr[r]), sq_sx));
+                    q = fminf(fmaxf(q, -sq_qmax - 1.f), sq_qmax);
+                    xr[i][r] = sq_sx != 0.f ? div_by_scale(q, sq_sx, sq_rsx) : q;
+                }
+        }
 #pragma unroll
         for (int i = 0; i < XI; ++i) {
             const int item = tid + 256 * i;
@@ -755,6 +776,7 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
                     opix = (size_t)(h * d + ij / d) * (a.Wo * d) + (w * d + ij % d);
                 }
                 float t = __fadd_rn(acc[i][j][r], __fmul_rn(accl[i][j][r], 1.0f / 2048.f));
+                if (SQ) t = __fmul_rn(t, a.out_mul[oc]);
                 if (a.bias) t = __fadd_rn(t, a.bias[oc]);
                 if (a.post_scale) t = __fadd_rn(__fmul_rn(t, a.post_scale[oc]), a.post_shift[oc]);
                 if (a.relu) t = fmaxf(t, 0.f);
@@ -843,6 +865,55 @@ extern "C" int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *probs, int32_t n
         hipLaunchKernelGGL((conv2d_f32_kernel<2, 2, 4, 2, 16>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 128), n), dim3(256), 0, stream, grp);
     }
     AQ3D_CHECK_LAUNCH("aq3d_conv2d_f32");
+    return AQ3D_OK;
+}
+
+// codes of aq3d_sq_prep -> fp32 (exact), weight step 1 / scale_w per output channel (scale_w = qmax_w / amax_w, 1 where amax_w <= 2^-24)
+__global__ __launch_bounds__(256) void sq16_expand_kernel(const int8_t *__restrict__ wq, const float *__restrict__ amax_w, int Cout, int K,
+                                                          float qmax_w, float *__restrict__ wf, float *__restrict__ wstep) {
+    const long long total = (long long)Cout * K;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) wf[t] = (float)wq[t];
+    if (blockIdx.x == 0)
+        for (int o = threadIdx.x; o < Cout; o += 256) {
+            const float am = amax_w[o];
+            wstep[o] = am <= 1.0f / (float)(1 << 24) ? 1.f : __fdiv_rn(1.0f, __fdiv_rn(qmax_w, am));
+        }
+}
+
+extern "C" size_t aq3d_conv2d_sq16_workspace_bytes(int32_t Cin, int32_t Cout, int32_t ksize) {
+    return sq_align((size_t)Cout * Cin * ksize * ksize * 4) + sq_align((size_t)Cout * 4);
+}
+
+extern "C" int aq3d_conv2d_sq16(const float *x, const void *params, const aq3d_conv2d_geom *g, int32_t w_bits, int32_t a_bits,
+                                const float *bias, const float *post_scale, const float *post_shift, float *y, void *workspace,
+                                size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(x && params && g && y && workspace, "aq3d_conv2d_sq16: null argument");
+    AQ3D_REQUIRE(a_bits > 8 && a_bits <= 16 && w_bits >= 2 && w_bits <= 8, "aq3d_conv2d_sq16: bits w=%d a=%d (8-bit activations run on aq3d_conv2d_i8)", w_bits, a_bits);
+    AQ3D_REQUIRE((g->Cin & 31) == 0 && g->deconv == 0, "aq3d_conv2d_sq16: Cin=%d must be a multiple of 32, no deconv", g->Cin);
+    if (workspace_bytes < aq3d_conv2d_sq16_workspace_bytes(g->Cin, g->Cout, g->ksize)) {
+        aq3d_set_error("aq3d_conv2d_sq16: workspace too small");
+        return AQ3D_ERR_WORKSPACE;
+    }
+    const int K = g->Cin * g->ksize * g->ksize;
+    const SqLayout l = sq_layout(g->Cin, g->Cout, g->ksize);
+    const char *base = (const char *)params;
+    float *wf = (float *)workspace;
+    float *wstep = (float *)((char *)workspace + sq_align((size_t)g->Cout * K * 4));
+    hipLaunchKernelGGL(sq16_expand_kernel, dim3(aq3d_grid((int64_t)g->Cout * K, 256, 1024)), dim3(256), 0, stream, (const int8_t *)(base + l.wq),
+                       (const float *)(base + l.amaxw), g->Cout, K, (float)((1 << (w_bits - 1)) - 1), wf, wstep);
+    aq3d_conv2d_problem q;
+    q.x = x; q.weight_or_params = wf; q.geom = g; q.bias = bias; q.post_scale = post_scale; q.post_shift = post_shift;
+    q.y = y; q.pieces_out = nullptr; q.pieces_ld = 0; q.pieces_mode = 0;
+    ConvGroup grp;
+    int L = 0;
+    int rc = prep_f32(&grp.p[0], &q, &L);
+    if (rc != AQ3D_OK) return rc;
+    grp.p[0].s = (const float *)(base + l.s); grp.p[0].rinv = (const float *)(base + l.r); grp.p[0].scal = (const float *)(base + l.scal);
+    grp.p[0].out_mul = wstep;
+    for (int i = 1; i < AQ3D_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
+    hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 32, true>), dim3(aq3d_div_up(L, 64), aq3d_div_up(g->Cout, 64), 1), dim3(256), 0, stream, grp);
+    AQ3D_CHECK_LAUNCH("aq3d_conv2d_sq16");
     return AQ3D_OK;
 }
 

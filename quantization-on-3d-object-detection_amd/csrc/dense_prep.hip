@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void sq_weights_kernel(SqGroup grp, int K, flo
     float sx = __fdiv_rn(qmax_a, amax_x), dvx = sx;
     if (amax_x <= eps) { sx = 0.f; dvx = 1.f; }
     const float inv_sx = __fdiv_rn(1.0f, dvx);
-    if (oc == 0 && threadIdx.x == 0) { q.scal[0] = sx; q.scal[1] = amax_x; q.scal[2] = inv_sx; q.scal[3] = q.static_amax_x > 0.f ? 1.f : 0.f; }
+    if (oc == 0 && threadIdx.x == 0) { q.scal[0] = sx; q.scal[1] = amax_x; q.scal[2] = inv_sx; q.scal[3] = q.static_amax_x > 0.f ? 1.f : 0.f; q.scal[4] = qmax_a; }
     const float *wrow = q.weight + (size_t)oc * K;
     float mx = 0.f;
     for (int j = threadIdx.x; j < K; j += 256) mx = fmaxf(mx, fabsf(__fmul_rn(wrow[j], q.s[j])));
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(SQ_FUSED_THREADS) void sq_prep_row_kernel(SqGroup g
     if (amax_x <= eps) { sx = 0.f; dvx = 1.f; }
     const float inv_sx = __fdiv_rn(1.0f, dvx);
     if (pub && threadIdx.x == 0) {
-        q.scal[0] = sx; q.scal[1] = amax_x; q.scal[2] = inv_sx; q.scal[3] = q.static_amax_x > 0.f ? 1.f : 0.f;
+        q.scal[0] = sx; q.scal[1] = amax_x; q.scal[2] = inv_sx; q.scal[3] = q.static_amax_x > 0.f ? 1.f : 0.f; q.scal[4] = qmax_a;
         if (amax_dyn > 0.f && amax_dyn > *q.amax_x_acc) aq3d_atomic_max_pos(q.amax_x_acc, amax_dyn);
     }
     float mx = 0.f;
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(SQ_FUSED_THREADS) void sq_prep_row_kernel(SqGroup g
 extern "C" int aq3d_sq_prep_group(const aq3d_sq_prep_problem *probs, int32_t n, int32_t w_bits, int32_t a_bits, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AQ3D_REQUIRE(probs && n >= 1 && n <= AQ3D_SQ_MAX_GROUP, "aq3d_sq_prep_group: n=%d not in 1..%d", n, AQ3D_SQ_MAX_GROUP);
-    AQ3D_REQUIRE(w_bits >= 2 && w_bits <= 8 && a_bits >= 2 && a_bits <= 8, "aq3d_sq_prep: int8 kernel needs bits <= 8 (w=%d a=%d)", w_bits, a_bits);
+    AQ3D_REQUIRE(w_bits >= 2 && w_bits <= 8 && a_bits >= 2 && a_bits <= 16, "aq3d_sq_prep: w_bits <= 8, a_bits <= 16 (w=%d a=%d)", w_bits, a_bits);
     const aq3d_conv2d_geom *g = probs[0].geom;
     AQ3D_REQUIRE(g, "aq3d_sq_prep: null argument");
     AQ3D_REQUIRE(g->ksize == 1 || g->ksize == 3, "aq3d_sq_prep: ksize=%d", g->ksize);

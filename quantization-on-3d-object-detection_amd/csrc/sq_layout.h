@@ -1,6 +1,7 @@
 // Layout of the per-layer, per-frame SmoothQuant parameter block (written by aq3d_sq_prep, read by aq3d_conv2d_i8).
 //   s f32[K] | rinv f32[K] | out_mul f32[Cout] | amax_w f32[Cout] | scal f32[64] | wq i8[Cout*K]     (256-B aligned parts)
-//   scal[0] = activation quant scale sx (0 if amax_x <= 2^-24), scal[1] = amax_x, scal[2] = 1/sx
+//   scal[0] = activation quant scale sx (0 if amax_x <= 2^-24), scal[1] = amax_x, scal[2] = 1/sx, scal[3] = static-amax flag,
+//   scal[4] = qmax of the activation quantiser (127, or 32767 for the 16-bit path)
 #pragma once
 #include <stddef.h>
 

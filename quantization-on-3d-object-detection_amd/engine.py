@@ -470,14 +470,18 @@ class Engine:
                 Ho, Wo = g.Ho, g.Wo
                 wk = ops.conv_weight_to_k(mod.weight.detach().float())
                 is_q = isinstance(mod, _QuantConv2dBase) and mod._input_quantizer._if_quant
-                if is_q and (cin % 64 != 0 or mod._weight_quantizer.num_bits > 8 or mod._input_quantizer.num_bits > 8):
-                    raise NotImplementedError("int8 dense conv needs Cin %% 64 == 0 and <= 8 bits (%s)" % path)
+                if is_q and (cin % 64 != 0 or mod._weight_quantizer.num_bits > 8 or mod._input_quantizer.num_bits > 16):
+                    raise NotImplementedError("quantised dense conv needs Cin %% 64 == 0, w_bits <= 8, act_bits <= 16 (%s)" % path)
                 if is_q:
                     cpad = (cout + 3) // 4 * 4
                     if cpad != cout:    # pad the output channels to the 16-byte store granularity
                         wk = torch.cat([wk, torch.zeros((cpad - cout, wk.shape[1]), device=wk.device)], 0)
                         g.Cout = cpad
-                    rec["kind"] = "i8"
+                    # more than 8 activation bits (the reference's A16): fake-quantised values on the fp16 pipe (aq3d_conv2d_sq16)
+                    rec["kind"] = "i8" if mod._input_quantizer.num_bits <= 8 else "sq16"
+                    if rec["kind"] == "sq16":
+                        rec["sq16_ws"] = torch.empty((ops._lib.load().aq3d_conv2d_sq16_workspace_bytes(cin, g.Cout, k),),
+                                                     dtype=torch.uint8, device=dev)
                     rec["weight"] = wk.contiguous().to(dev)
                     rec["w_colmax"] = rec["weight"].abs().max(dim=0)[0].contiguous()
                     rec["alpha"] = mod.scaling_factor
@@ -496,7 +500,7 @@ class Engine:
                                 p_["pieces_out"] = (self._pieces[pkey], cin, 1)
                             self._pieces_mode[pkey] = 1
                             rec["pieces_owner"] = False
-                        elif fusable and all(p_["kind"] != "i8" for p_ in prods):
+                        elif fusable and all(p_["kind"] == "f32" for p_ in prods):
                             for p_ in prods:        # fp32 producers (deblocks → bev_cat): exact classes, merged per workgroup in LDS
                                 p_["pieces_out"] = (self._pieces[pkey], cin, 0)
                             rec["pieces_owner"] = False
@@ -730,7 +734,7 @@ class Engine:
             while j + 1 < len(order) and j + 1 - i < 8 and sig(recs[order[j + 1]]) == sig(recs[order[i]]):
                 j += 1
             grp = [recs[k] for k in order[i:j + 1]]
-            if len(grp) == 1 or grp[0].get("calib") is not None:
+            if len(grp) == 1 or grp[0].get("calib") is not None or grp[0]["kind"] == "sq16":
                 new_steps.extend(("conv2d", r) for r in grp)
             else:
                 new_steps.append(("conv2d_group", self._make_group(grp, B)))
@@ -941,7 +945,7 @@ class Engine:
         po = None
         if rec["pieces_out"] is not None:
             po = self.arena.view(rec["pieces_out"][0], (16, rec["pieces_out"][1]))
-        if rec["kind"] == "i8":
+        if rec["kind"] in ("i8", "sq16"):
             pieces = self.arena.view(rec["pieces"], (16, g.Cin))
             if rec["pieces_owner"]:
                 with _Timed(self, "piece_absmax"):
@@ -950,6 +954,12 @@ class Engine:
             with _Timed(self, "sq_prep"):
                 ops.sq_prep(pieces, rec["weight"], rec["w_colmax"], g, rec["alpha"], rec["params"], rec["w_bits"],
                             rec["a_bits"], rec["static_x"], rec["static_w"], self.arena.view(rec["amax_x_acc"]))
+            if rec["kind"] == "sq16":
+                with _Timed(self, "conv2d_sq16"):
+                    for b in range(B):
+                        ops.conv2d_sq16(x[b], rec["params"], g, rec["w_bits"], rec["a_bits"], rec["bias"], rec["post_scale"],
+                                        rec["post_shift"], out=out[b], workspace=rec["sq16_ws"])
+                return
             with _Timed(self, "conv2d_i8"):
                 for b in range(B):
                     ops.conv2d_i8(x[b], rec["params"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b],
@@ -1007,7 +1017,7 @@ class Engine:
         self.bev_cat[:B].copy_(bev_nhwc)
         # the piece maxima of bev_cat normally come out of the deblock epilogues, which do not run here
         for kind, rec in self.steps[self.head_first_step:]:
-            if kind == "conv2d" and rec["kind"] == "i8" and rec["x"] is self.bev_cat and not rec["pieces_owner"]:
+            if kind == "conv2d" and rec["kind"] in ("i8", "sq16") and rec["x"] is self.bev_cat and not rec["pieces_owner"]:
                 g = rec["geom"]
                 for b in range(B):
                     ops.piece_absmax(self.bev_cat[b], g.H, g.W, g.Cin, g.in_ld, self.arena.view(rec["pieces"], (16, g.Cin)))

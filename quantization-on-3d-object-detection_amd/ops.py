@@ -326,6 +326,18 @@ def _addr(t):
     return None if t is None else t.data_ptr()
 
 
+def conv2d_sq16(x, params, g, w_bits, a_bits, bias=None, post_scale=None, post_shift=None, out=None, workspace=None):
+    """SQConv2d with 9..16 activation bits on fake-quantised values (aq3d_conv2d_sq16); params from sq_prep(a_bits=...)."""
+    L = _lib.load()
+    need = L.aq3d_conv2d_sq16_workspace_bytes(g.Cin, g.Cout, g.ksize)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty((need,), dtype=torch.uint8, device=x.device)
+    y = out if out is not None else torch.empty((g.Ho, g.Wo, g.out_ld), dtype=f32, device=x.device)
+    check(L.aq3d_conv2d_sq16(_pv(x), _p(params), ctypes.byref(g), int(w_bits), int(a_bits), _p(bias), _p(post_scale), _p(post_shift),
+                             _pv(y), _p(workspace), workspace.numel(), _stream()), "aq3d_conv2d_sq16")
+    return y
+
+
 def conv_problems(recs):
     """ctypes array of aq3d_conv2d_problem from dicts(x, w, g, bias, post_scale, post_shift, y, pieces_out, pieces_mode)."""
     arr = (_lib.Conv2dProblem * len(recs))()

@@ -1,0 +1,46 @@
+"""HBM-side bytes per launch of every kernel family from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (counters in KB;
+FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950: it counts 64 B per 128-byte request on wide coalesced reads).
+usage: pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass>  → JSON on stdout (profiles/pmc_traffic.json)."""
+import collections, csv, glob, json, sys
+
+FAMILY = [("conv2d_i8_kernel", "conv2d_i8"), ("conv2d_f16s_kernel", "conv2d_f32"), ("conv2d_f32_kernel", "conv2d_f32"),
+          ("sp_prep_kernel", "quantize_rows"), ("quantize_rows_kernel", "quantize_rows"), ("piece_absmax_kernel", "piece_absmax"),
+          ("sq_prep", "sq_prep"), ("sq_scales", "sq_prep"), ("sq_weights", "sq_prep"), ("scatter_dense_kernel", "scatter_dense"),
+          ("vox_", "voxelize")]
+
+
+def family(name):
+    if "spconv_c" in name or "spconv_kernel" in name or "spconv_stem" in name or "spconv_f16w" in name:
+        import re
+        m = re.search(r"spconv_c[dw]_kernel<(\d+), (\d+)", name)           # cd<COUT, KVOL, NW>, cw<CIN, COUT>
+        if m:
+            return "spconv_c%d" % (int(m.group(1)) if "spconv_cd" in name else int(m.group(2)))
+        return "spconv_other"
+    for key, fam in FAMILY:
+        if key in name:
+            return fam
+    return None
+
+
+def collect(d, counter):
+    tot, n = collections.Counter(), collections.Counter()
+    for f in glob.glob(d + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            fam = family(r["Kernel_Name"])
+            if fam:
+                tot[fam] += float(r["Counter_Value"]) * 1024.0
+                n[fam] += 1
+    return tot, n
+
+
+fetch, nf = collect(sys.argv[1], "FETCH_SIZE")
+write, nw = collect(sys.argv[2], "WRITE_SIZE")
+out = {"_note": "HBM-side bytes per launch: (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / launches, separate rocprofv3 --pmc passes of "
+                "`bench.py --steps 3 --warmup 2` with eager launches (scratch/prof_all.sh); FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                "(gfx950 counts 64 B per 128-byte request); family averages over all launches of the family in the profiled frames"}
+for fam in sorted(set(fetch) | set(write)):
+    out[fam] = (2.0 * fetch[fam] / max(nf[fam], 1)) + write[fam] / max(nw[fam], 1)
+    out["_" + fam + "_fetch_write_launches"] = [2.0 * fetch[fam] / max(nf[fam], 1), write[fam] / max(nw[fam], 1), nf[fam]]
+print(json.dumps(out, indent=1))

@@ -111,7 +111,7 @@ def dense_layers(eng, oracle_nchw, B=1):
         nhwc = t.permute(0, 2, 3, 1).contiguous()
         assert tuple(nhwc.shape[:3]) == tuple(x.shape[:3]) and nhwc.shape[3] <= x.shape[3], (rec["path"], nhwc.shape, x.shape)
         x[:B, :, :, :nhwc.shape[3]].copy_(nhwc.to(dev))
-        if rec["kind"] == "i8":
+        if rec["kind"] in ("i8", "sq16"):
             g = rec["geom"]
             pieces = eng.arena.view(rec["pieces"], (16, g.Cin))
             for b in range(B):

@@ -205,3 +205,37 @@ def test_prevoxelized_batch_dict_and_mean_vfe(dev):
     with pytest.raises(ValueError, match="capacity"):
         with torch.no_grad():
             model(batch)
+
+
+def test_w8a16_teacher_forced(dev):
+    """The reference's "16-bit activation preservation" (README.md:10,21): quant(model, w_bits=8, act_bits=16, sq=True). Sparse
+    layers run on fp32 fake-quantised rows (65 535-level codes do not fit a byte), SQConv2d layers on fake-quantised values on the
+    fp16 pipe (aq3d_conv2d_sq16). Every layer on the oracle's input, bar 2e-5 of its output scale; and A16 is closer to the
+    fp32 model than A8 is (what the reference keeps the 16 bits for)."""
+    import teacher
+    from amdq3d import quant as Qz
+    cfg = small_cfg("waymo")
+    ds, model = build_model(cfg, n_points=9000, n_voxels=2500)
+    state = _state(model)
+    Qz.quant(model, 8, 16, sq=True, alpha=0.5, static=False)
+    model.cuda()
+    _run_gpu(model, ds, 0, dev)
+    pts = ds[0]["points"]
+    trace, trace8, trace32 = {}, {}, {}
+    OC.run(state, cfg, pts, OC.Recipe(8, 16, True, 0.5), trace)
+    OC.run(state, cfg, pts, OC.Recipe(8, 8, True, 0.5), trace8)
+    OC.run(state, cfg, pts, None, trace32)
+    eng = model.engine()
+    assert sum(r["kind"] == "sq16" for r in eng.dense_convs) == 17 and not any(r.get("coded") for r in eng.sparse_convs)
+    idx_sets = [trace["vfe"][1]] + [trace["levels"][n][1] for n in ("x_conv2", "x_conv3", "x_conv4")] + [trace["encoded"][1]]
+    maps = teacher.row_maps(eng, idx_sets)
+    res = teacher.sparse_layers(eng, maps, lambda n: trace["vfe"][0] if n == "vfe" else trace[n])
+    res += teacher.dense_layers(eng, lambda n: trace[n])
+    teacher.report("w8a16, teacher-forced layers", res)
+    bad = [(p, e) for p, k, e, _ in res if not e <= 2e-5]
+    assert not bad, bad
+    rms = lambda a: float(np.sqrt(np.mean(np.square(a.numpy().astype(np.float64)))))
+    ref = trace32["spatial_features_2d"]
+    e16, e8 = rms(trace["spatial_features_2d"] - ref), rms(trace8["spatial_features_2d"] - ref)
+    print("BEV rms error vs fp32: w8a16 %.3e, w8a8 %.3e" % (e16, e8))
+    assert e16 < e8
