@@ -36,7 +36,7 @@ def smooth_scale(act_scale, w_scale, alpha):
 
 
 def sq_conv2d(x, weight, bias, stride, padding, alpha, w_bits=8, a_bits=8, amax_x=None, amax_w=None, return_stats=False,
-              quantize=True):
+              quantize=True, scale_override=None):
     """x [B,C,H,W], weight [O,I,k,k]. alpha=None → no smoothing (plain per-tensor act / per-oc weight fake quant).
     amax_x / amax_w: calibrated amax (static PTQ: values beyond them clip at -2^(b-1) / 2^(b-1)-1). quantize=False is the
     calibration forward of quant/quantize.py:175-195 (quantizers disabled, calibrators enabled): the smoothed operands go
@@ -51,6 +51,10 @@ def sq_conv2d(x, weight, bias, stride, padding, alpha, w_bits=8, a_bits=8, amax_
         w_scale = w.abs().max(dim=0)[0]
         act_scale = cols.abs().max(dim=0)[0]
         scale = smooth_scale(act_scale, w_scale, alpha)
+        if return_stats:
+            ieee_scale = scale
+        if scale_override is not None:      # golden-vector tests: the scale bits the reference's torch build produced
+            scale = torch.as_tensor(scale_override, dtype=torch.float32)
         w = w * scale
         cols = cols / scale
     aw = Q.reduce_amax(w.numpy(), axis=0) if amax_w is None else np.asarray(amax_w, np.float32).reshape(O, 1)
@@ -65,7 +69,7 @@ def sq_conv2d(x, weight, bias, stride, padding, alpha, w_bits=8, a_bits=8, amax_
     if bias is not None:
         y = y + bias.view(1, O, 1, 1)
     if return_stats:
-        return y, {"amax_x": np.float32(ax), "amax_w": aw.reshape(-1)}
+        return y, {"amax_x": np.float32(ax), "amax_w": aw.reshape(-1), "scale": None if alpha is None else ieee_scale.numpy()}
     return y
 
 

@@ -61,8 +61,15 @@ def make_sqconv(sm, cin, cout, H, W, stride, padding, alpha, seed, bias=True):
     x = torch.relu(torch.randn(1, cin, H, W, generator=g)) * (torch.rand(1, cin, 1, 1, generator=g) * 3 + 0.1)
     with torch.no_grad():
         y = inst.forward(x.clone())
+        # the smoothing scale exactly as smoothquant.py:69-76 computes it (same expressions, same torch build, same machine): torch's
+        # CPU pow is not correctly rounded, so this is what pins WHICH last bit the golden output was made with
+        cols = torch.nn.functional.unfold(x, kernel_size=3, dilation=1, padding=padding, stride=stride).permute(0, 2, 1).reshape(-1, cin * 9)
+        w_scale = torch.max(conv.weight.view(cout, cin * 9).abs().detach(), dim=0)[0]
+        act_scale = torch.max(cols.abs().detach(), dim=0)[0]
+        scale = act_scale ** alpha / w_scale ** (1 - alpha)
+        scale[scale == 0] = 1
     return dict(x=x.numpy(), weight=conv.weight.detach().numpy(), bias=conv.bias.detach().numpy() if bias else np.zeros(0, np.float32),
-                y=y.numpy(), stride=np.int64(stride), padding=np.int64(padding), alpha=np.float64(alpha))
+                y=y.numpy(), stride=np.int64(stride), padding=np.int64(padding), alpha=np.float64(alpha), scale_torch=scale.numpy())
 
 
 def main():
@@ -70,6 +77,8 @@ def main():
     np.savez_compressed(os.path.join(HERE, "sqconv2d_16x8.npz"), **make_sqconv(sm, 16, 8, 12, 10, 1, 1, 0.5, 1))
     np.savez_compressed(os.path.join(HERE, "sqconv2d_64x32_s2.npz"), **make_sqconv(sm, 64, 32, 16, 14, 2, 1, 0.5, 2, bias=False))
     np.savez_compressed(os.path.join(HERE, "sqconv2d_32x16_a03.npz"), **make_sqconv(sm, 32, 16, 9, 11, 1, 1, 0.3, 3))
+    np.savez_compressed(os.path.join(HERE, "sqconv2d_128x64.npz"), **make_sqconv(sm, 128, 64, 14, 12, 1, 1, 0.5, 4))
+    np.savez_compressed(os.path.join(HERE, "sqconv2d_256x128_s2.npz"), **make_sqconv(sm, 256, 128, 12, 12, 2, 1, 0.5, 5))
 
     bb = _load(os.path.join(REF, "pcdet/models/backbones_2d/base_bev_backbone.py"), "ref_bev")
 

@@ -15,22 +15,32 @@ from oracle import voxel as OV
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("name", ["sqconv2d_16x8", "sqconv2d_64x32_s2", "sqconv2d_32x16_a03"])
+@pytest.mark.parametrize("name", ["sqconv2d_16x8", "sqconv2d_64x32_s2", "sqconv2d_32x16_a03", "sqconv2d_128x64", "sqconv2d_256x128_s2"])
 def test_sqconv2d_restatement_vs_reference_class(name):
-    """Golden = quant/smoothquant.py::SQConv2d.forward run in the build container. The restatement differs from it only
-    through torch-CPU's last-bit-inexact sqrt/pow in the smoothing scale (oracle/dense.py::smooth_scale), which can move
-    isolated integer codes by one step: >= 99.5 % of the outputs agree to 1e-5 and none is off by more than 3 code steps."""
+    """Golden = quant/smoothquant.py::SQConv2d.forward run in the build container (tests/golden/make_golden.py).
+    (a) With the smoothing scale the reference's torch build produced (stored beside the output), the restatement reproduces the
+        reference output everywhere: the unfold / smoothing / fake-quant / matmul flow is pinned with no tolerance for outliers.
+    (b) The only liberty the restatement takes is IEEE sqrt / pow in the smoothing scale (oracle/dense.py::smooth_scale; torch's
+        CPU pow is not correctly rounded and varies with the host's SIMD level): its scale differs from the stored one by at most
+        two ulps per column (two square roots and a quotient), and with it every output stays within 3 code steps (a last-bit
+        change of the scale moves isolated integer codes)."""
     z = np.load(os.path.join(GOLD, name + ".npz"))
     x, w = torch.from_numpy(z["x"]), torch.from_numpy(z["weight"])
     b = torch.from_numpy(z["bias"]) if z["bias"].size else None
-    y, st = ODN.sq_conv2d(x, w, b, int(z["stride"]), int(z["padding"]), float(z["alpha"]), return_stats=True)
     ref = z["y"]
-    assert y.shape == ref.shape
+    scale_ref = z["scale_torch"]
+    sc = max(1.0, float(np.abs(ref).max()))
+    y0, _ = ODN.sq_conv2d(x, w, b, int(z["stride"]), int(z["padding"]), float(z["alpha"]), return_stats=True, scale_override=scale_ref)
+    assert y0.shape == ref.shape
+    assert np.abs(y0.numpy() - ref).max() <= 1e-5 * sc                                 # (a) every element
+    y, st = ODN.sq_conv2d(x, w, b, int(z["stride"]), int(z["padding"]), float(z["alpha"]), return_stats=True)
+    ulps = np.abs(st["scale"].view(np.int32).astype(np.int64) - scale_ref.view(np.int32).astype(np.int64))
+    assert ulps.max() <= 2, ulps.max()                                                  # (b) the scale: last-bit differences only
     d = np.abs(y.numpy() - ref)
-    scale = max(1.0, float(np.abs(ref).max()))
-    step = float(st["amax_x"]) / 127 * float(st["amax_w"].max()) / 127 * 127      # one activation code x a full-scale weight
-    assert (d <= 1e-5 * scale).mean() >= 0.995
+    step = float(st["amax_x"]) / 127 * float(st["amax_w"].max()) / 127 * 127           # one activation code x a full-scale weight
     assert d.max() <= 3 * step
+    if ulps.max() == 0:
+        assert d.max() <= 1e-5 * sc
 
 
 def test_bev_backbone_restatement_vs_reference_class():
