@@ -4,7 +4,7 @@ name=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for kv in "$@"; do export "$kv"; done
 rm -rf gpurun_out/_stats
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_stats -- python3 bench.py --steps 40 --warmup 7 --no-cpu-baseline $BENCH_ARGS > gpurun_out/_stats.json 2> gpurun_out/_stats.err
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/_stats -- python3 bench.py --steps 40 --warmup 7 --no-cpu-baseline --no-accuracy $BENCH_ARGS > gpurun_out/_stats.json 2> gpurun_out/_stats.err
 python3 - "$name" <<'PY'
 import csv, glob, sys
 f = glob.glob("gpurun_out/_stats/**/*kernel_stats.csv", recursive=True)[0]
