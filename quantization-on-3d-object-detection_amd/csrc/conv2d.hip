@@ -36,6 +36,7 @@ struct ConvArgs {
     int pieces_ld;
     int pieces_mode;        // 0: 16 exact classes; 1: the four interior classes merged (all consumers have stride 1)
     int xcd_order;          // int8 generic kernel: pixel tiles dealt to XCDs in contiguous ranges (grid x padded to 8)
+    int nrb;                // fp16-pipe fp32 kernel: row (output-channel) blocks per pixel tile (1-D XCD-aware tile order)
 };
 
 // Up to 8 independent convolutions of one launch class in a single grid (blockIdx.z = problem): the head's per-branch convs
@@ -606,7 +607,16 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int WM, int WN, int TI, int TJ, int KS, bool SQ = false>
 __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
     const ConvArgs a = grp.p[blockIdx.z];
-    if ((int)blockIdx.y * WM * TI * 16 >= a.rows_total) return;
+    // Tile order: the row (output-channel) blocks of ONE pixel tile re-read the same input pixels, so they are dispatched back to
+    // back on the SAME XCD (workgroups go round-robin over the 8 XCDs, each with its own L2): id -> xcd = id % 8, j = id / 8,
+    // row block = j % NRB, pixel tile = (j / NRB) * 8 + xcd. With (pixel tile, row block) as (blockIdx.x, blockIdx.y) the 4-16 row
+    // blocks of a tile ran a whole grid row apart on arbitrary XCDs and each fetched its input again from beyond L2
+    // (PMC, round 2: 130 MB per launch for 21 MB of algorithmic traffic). gridDim.x = 8 * ceil(pixel tiles / 8) * NRB.
+    const int nrb = a.nrb;
+    const int bid = (int)blockIdx.x;
+    const int bj = bid >> 3;
+    const int rb = bj % nrb, pt = (bj / nrb) * 8 + (bid & 7);
+    if (rb * WM * TI * 16 >= a.rows_total) return;
     constexpr int BM = WM * TI * 16;
     constexpr int BN = WN * TJ * 16;
     constexpr int LD = 2 * KS + 8;  // halves per LDS row: KS hi | KS lo | 16 B pad
@@ -623,8 +633,9 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
     const int g = lane >> 4, l15 = lane & 15;
     const int L = a.Ho * a.Wo;
     const int K = a.Cin * a.ks * a.ks;
-    const int pix0 = blockIdx.x * BN;
-    const int row0 = blockIdx.y * BM;
+    const int pix0 = pt * BN;
+    const int row0 = rb * BM;
+    if (pix0 >= a.Ho * a.Wo) return;                     // padding of the pixel-tile count to a multiple of 8
     const int cchunks = a.Cin / KS;
     const int nk = a.ks * a.ks * cchunks;
 
@@ -850,9 +861,12 @@ extern "C" int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *probs, int32_t n
     for (int i = 0; i < n; ++i) split_ok = split_ok && (probs[i].geom->Cin & 31) == 0;
     if (split_ok) {     // fp16 matrix pipe, split operands (see conv2d_f16s_kernel)
         if (cls == 0) {
-            hipLaunchKernelGGL((conv2d_f16s_kernel<1, 4, 1, 2, 32>), dim3(aq3d_div_up(L, 128), 1, n), dim3(256), 0, stream, grp);
+            for (int i = 0; i < AQ3D_MAX_GROUP; ++i) grp.p[i].nrb = 1;
+            hipLaunchKernelGGL((conv2d_f16s_kernel<1, 4, 1, 2, 32>), dim3(aq3d_div_up(aq3d_div_up(L, 128), 8) * 8, 1, n), dim3(256), 0, stream, grp);
         } else {        // 64 x 64 tiles for both deblock shapes (128-row tiles measured slower: conversion work, 63 KB of LDS; 64-deep K steps: no gain)
-            hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 32>), dim3(aq3d_div_up(L, 64), aq3d_div_up(max_rows, 64), n), dim3(256), 0, stream, grp);
+            const int nrb = aq3d_div_up(max_rows, 64);
+            for (int i = 0; i < AQ3D_MAX_GROUP; ++i) grp.p[i].nrb = nrb;
+            hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 32>), dim3(aq3d_div_up(aq3d_div_up(L, 64), 8) * 8 * nrb, 1, n), dim3(256), 0, stream, grp);
         }
         AQ3D_CHECK_LAUNCH("aq3d_conv2d_f32");
         return AQ3D_OK;
@@ -911,8 +925,9 @@ extern "C" int aq3d_conv2d_sq16(const float *x, const void *params, const aq3d_c
     if (rc != AQ3D_OK) return rc;
     grp.p[0].s = (const float *)(base + l.s); grp.p[0].rinv = (const float *)(base + l.r); grp.p[0].scal = (const float *)(base + l.scal);
     grp.p[0].out_mul = wstep;
+    grp.p[0].nrb = aq3d_div_up(g->Cout, 64);
     for (int i = 1; i < AQ3D_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
-    hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 32, true>), dim3(aq3d_div_up(L, 64), aq3d_div_up(g->Cout, 64), 1), dim3(256), 0, stream, grp);
+    hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 32, true>), dim3(aq3d_div_up(aq3d_div_up(L, 64), 8) * 8 * grp.p[0].nrb, 1, 1), dim3(256), 0, stream, grp);
     AQ3D_CHECK_LAUNCH("aq3d_conv2d_sq16");
     return AQ3D_OK;
 }

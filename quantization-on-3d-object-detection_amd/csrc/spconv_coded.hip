@@ -287,34 +287,38 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
 // slice go through LDS (double buffered, XOR-swizzled 128-byte rows as in the round-1 wide kernel), the A fragments of the
 // wave's two 16-row tiles are gathered straight into registers: ONE bounded buffer load per row and unit (16 bytes = the
 // 8 + 8 channels of the lane's two K chunks; 8 bytes when Cin = 32), missing neighbour = out-of-range offset = zeros.
-template <int CIN, int COUT>
+template <int CIN, int COUT, int CT>
 __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
+    constexpr int NCB = COUT / CT;                      // column blocks: a workgroup computes CT of the COUT output channels
     constexpr int RT = 2;
     constexpr int TM = 4 * RT * 16;
-    constexpr int NT = COUT / 16;
+    constexpr int NT = CT / 16;
     constexpr int UC = CIN < 64 ? CIN : 64;
     constexpr int NU = CIN / UC;
     constexpr int KC = UC / 32;
     constexpr bool SWZ = UC == 64;
     constexpr int LDW = SWZ ? UC : UC + 8;              // halves per LDS weight row of one plane
-    constexpr int PCH = COUT * UC / 8;                  // 16-byte chunks of one plane of a unit
+    constexpr int PCH = CT * UC / 8;                  // 16-byte chunks of one plane of a unit
     constexpr int WCH = 2 * PCH;
     constexpr int NWL = (WCH + 255) / 256;
-    static_assert(CIN % 32 == 0 && COUT % 16 == 0, "channel granularity");
+    static_assert(CIN % 32 == 0 && CT % 16 == 0 && COUT % CT == 0, "channel granularity");
     static_assert(WCH % 256 == 0, "whole chunk rounds");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16 *Wb = reinterpret_cast<_Float16 *>(smem_raw);              // [2 buffers][2 planes][COUT][LDW]
-    int *nbr_s = reinterpret_cast<int *>(Wb + 4 * COUT * LDW);          // [TM][kvol]
-    float *red = reinterpret_cast<float *>(nbr_s + TM * 27);            // [4][COUT]
-    int *mask_s = reinterpret_cast<int *>(red + 4 * COUT);
+    _Float16 *Wb = reinterpret_cast<_Float16 *>(smem_raw);              // [2 buffers][2 planes][CT][LDW]
+    int *nbr_s = reinterpret_cast<int *>(Wb + 4 * CT * LDW);          // [TM][kvol]
+    float *red = reinterpret_cast<float *>(nbr_s + TM * 27);            // [4][CT]
+    int *mask_s = reinterpret_cast<int *>(red + 4 * CT);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
     const int kvol = a.kvol;
     int n = *a.count_out;
     if (n > a.cap_out) n = a.cap_out;
-    const int row0 = (int)blockIdx.x * TM;
+    // column blocks of one row tile are dispatched to the SAME XCD (workgroups round-robin over the 8 XCDs): they gather the same rows
+    const int bj = (int)blockIdx.x >> 3;
+    const int cb = bj % NCB, ob = cb * CT;
+    const int row0 = ((bj / NCB) * 8 + ((int)blockIdx.x & 7)) * TM;
     if (row0 >= n) return;
     const auto rsrc_f = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, (int)a.codes_bytes, 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.wp, 0, kvol * COUT * 2 * CIN * 2, 0x00020000);
@@ -357,7 +361,7 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
             const int t = tid + 256 * i;
             const int pl = t / PCH, r = t % PCH;
             const int c8 = r % (UC / 8), o = r / (UC / 8);
-            const unsigned off = (unsigned)((((k * COUT + o) * 2 + pl) * CIN + h * UC + c8 * 8) * 2);
+            const unsigned off = (unsigned)((((k * COUT + ob + o) * 2 + pl) * CIN + h * UC + c8 * 8) * 2);
             wn[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0);       // k = kvol is past the end of the tensor: zeros
         }
     };
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
             const int t = tid + 256 * i;
             const int pl = t / PCH, r = t % PCH;
             const int c8 = r % (UC / 8), o = r / (UC / 8);
-            *reinterpret_cast<i32x4v *>(Wb + ((b * 2 + pl) * COUT + o) * LDW + (SWZ ? (c8 ^ ((o >> 1) & 7)) : c8) * 8) = wn[i];
+            *reinterpret_cast<i32x4v *>(Wb + ((b * 2 + pl) * CT + o) * LDW + (SWZ ? (c8 ^ ((o >> 1) & 7)) : c8) * 8) = wn[i];
         }
     };
     auto readSrc = [&](int (&src)[RT], int k) {
@@ -414,11 +418,11 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
         constexpr int NF = KC * NT * 2;
         constexpr int FD = 4;
         const int c0 = SWZ ? (g ^ ((l15 >> 1) & 7)) : g;
-        const _Float16 *bb = Wb + (b * 2 * COUT + l15) * LDW;
+        const _Float16 *bb = Wb + (b * 2 * CT + l15) * LDW;
         auto frag = [&](int j) {
             const int pl = j & 1, nt = (j >> 1) % NT, kc = (j >> 1) / NT;
             const int c = SWZ ? (c0 ^ (kc * 4)) : (c0 + kc * 4);
-            return *reinterpret_cast<const f16x8 *>(bb + (pl * COUT + nt * 16) * LDW + c * 8);
+            return *reinterpret_cast<const f16x8 *>(bb + (pl * CT + nt * 16) * LDW + c * 8);
         };
         f16x8 fb[FD + 1];
 #pragma unroll
@@ -464,7 +468,7 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
     float cmax[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int o = nt * 16 + l15;
+        const int o = ob + nt * 16 + l15;
         const float mul = a.out_mul[o];
         const float bs = a.bias ? a.bias[o] : 0.f;
         const float ps = a.post_scale ? a.post_scale[o] : 1.f;
@@ -495,190 +499,12 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
     if (a.absmax_out) {
         if (g == 0) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) red[wave * COUT + nt * 16 + l15] = cmax[nt];
+            for (int nt = 0; nt < NT; ++nt) red[wave * CT + nt * 16 + l15] = cmax[nt];
         }
         __syncthreads();
-        for (int o = tid; o < COUT; o += 256) {
-            const float mx = fmaxf(fmaxf(red[o], red[COUT + o]), fmaxf(red[2 * COUT + o], red[3 * COUT + o]));
-            if (mx > a.absmax_out[o]) aq3d_atomic_max_pos(&a.absmax_out[o], mx);
-        }
-    }
-}
-
-// Column-split variant for Cout >= 64: every wave computes ALL 128 rows of the tile for its own Cout / 4 output columns.
-// The row-split kernel above makes each of the 4 waves read every weight fragment of a unit from LDS (COUT x 64 channels x 2
-// planes = 32 KB per wave and unit at Cout = 128, 160 KB per workgroup and unit with the staging writes) against 64 MFMAs of 16
-// cycles: it is bound by LDS bandwidth — one workgroup alone takes ~2 200 cycles per unit, and two co-resident workgroups take
-// twice as long (measured: 98 us for 299 tiles whether a CU holds one tile or two). Here a weight fragment is read by ONE wave and
-// feeds 8 MFMAs (the 8 row tiles): 8 fragment reads per wave and unit, 64 KB of LDS traffic per workgroup and unit. The price
-// is that all 4 waves gather the same 128 code rows (8 x 16-byte loads per lane and unit instead of 2; the repeats hit L1/L2).
-template <int CIN, int COUT>
-__global__ __launch_bounds__(256) void spconv_cw2_kernel(SpCodedArgs a) {
-    constexpr int RT = 8;                               // 16-row tiles per wave = the whole 128-row tile
-    constexpr int TM = 128;
-    constexpr int NTW = COUT / 64;                      // 16-column tiles per wave
-    constexpr int UC = 64, NU = CIN / 64, KC = 2;
-    constexpr int LDW = 64;                             // halves per LDS weight row of one plane (128 B, XOR-swizzled chunks)
-    constexpr int PCH = COUT * UC / 8;
-    constexpr int WCH = 2 * PCH;
-    constexpr int NWL = WCH / 256;
-    static_assert(CIN % 64 == 0 && COUT % 64 == 0 && WCH % 256 == 0, "channel granularity");
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16 *Wb = reinterpret_cast<_Float16 *>(smem_raw);              // [2 buffers][2 planes][COUT][LDW]
-    int *nbr_s = reinterpret_cast<int *>(Wb + 4 * COUT * LDW);          // [TM][kvol]
-    int *mask_s = nbr_s + TM * 27;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, l15 = lane & 15;
-    const int kvol = a.kvol;
-    int n = *a.count_out;
-    if (n > a.cap_out) n = a.cap_out;
-    const int row0 = (int)blockIdx.x * TM;
-    if (row0 >= n) return;
-    const auto rsrc_f = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, (int)a.codes_bytes, 0x00020000);
-    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.wp, 0, kvol * COUT * 2 * CIN * 2, 0x00020000);
-
-    if (tid == 0) mask_s[0] = 0;
-    {
-        const int rows = n - row0 < TM ? n - row0 : TM;
-        const auto rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void *)(a.nbr + (size_t)row0 * kvol), 0, rows * kvol * 4, 0x00020000);
-        int v[(TM * 27 + 255) / 256];
-#pragma unroll
-        for (int i = 0; i < (TM * 27 + 255) / 256; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_n, (tid + 256 * i) * 4, 0, 0);
-        const int lim = rows * kvol;
-#pragma unroll
-        for (int i = 0; i < (TM * 27 + 255) / 256; ++i) {
-            const int t = tid + 256 * i;
-            if (t < TM * kvol) nbr_s[t] = t < lim ? v[i] : -1;
-        }
-    }
-    __syncthreads();
-    if (tid < TM) {
-        int bits = 0;
-        for (int k = 0; k < kvol; ++k)
-            if (nbr_s[tid * kvol + k] >= 0) bits |= 1 << k;
-        if (bits) atomicOr(&mask_s[0], bits);
-    }
-    __syncthreads();
-    const int live = mask_s[0];
-
-    f32x4 acc[RT][NTW];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    i32x4v A0[RT], A1[RT], wn[NWL];
-    auto loadW = [&](int k, int h) {
-#pragma unroll
-        for (int i = 0; i < NWL; ++i) {
-            const int t = tid + 256 * i;
-            const int pl = t / PCH, r = t % PCH;
-            const int c8 = r % (UC / 8), o = r / (UC / 8);
-            const unsigned off = (unsigned)((((k * COUT + o) * 2 + pl) * CIN + h * UC + c8 * 8) * 2);
-            wn[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0);       // k = kvol is past the end of the tensor: zeros
-        }
-    };
-    auto storeW = [&](int b) {
-#pragma unroll
-        for (int i = 0; i < NWL; ++i) {
-            const int t = tid + 256 * i;
-            const int pl = t / PCH, r = t % PCH;
-            const int c8 = r % (UC / 8), o = r / (UC / 8);
-            *reinterpret_cast<i32x4v *>(Wb + ((b * 2 + pl) * COUT + o) * LDW + (c8 ^ ((o >> 1) & 7)) * 8) = wn[i];
-        }
-    };
-    auto loadA = [&](i32x4v (&A)[RT], int k, int h) {
-        const int kk = k < kvol ? k : 0;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const int v = nbr_s[(rt * 16 + l15) * kvol + kk];
-            const int src = k < kvol ? v : -1;
-            const unsigned off = src >= 0 ? (unsigned)src * (unsigned)CIN + (unsigned)(h * 64 + 16 * g) : CD_OOB;
-            A[rt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, off, 0, 0);
-        }
-    };
-    auto next_unit = [&](int &k, int &h) {
-        if (k >= kvol) return;
-        if (h + 1 < NU) { ++h; return; }
-        h = 0;
-        const int rest = live & ~((2 << k) - 1);
-        k = rest ? (__ffs(rest) - 1) : kvol;
-    };
-    // One unit: this wave's 2 * NTW * 2 weight fragments (kc, nt, plane) come from LDS once; every row tile converts its 16 codes
-    // and issues 4 * NTW MFMAs. The next unit's weight loads and gathers are issued first so that they fly under the MFMAs.
-    auto unit = [&](i32x4v (&Acur)[RT], i32x4v (&Anext)[RT], int b, int &k, int &h) {
-        next_unit(k, h);                                 // (k, h) now names the NEXT unit
-        loadW(k, h);
-        loadA(Anext, k, h);
-        const int c0 = g ^ ((l15 >> 1) & 7);
-        const _Float16 *bb = Wb + (b * 2 * COUT + wave * (16 * NTW) + l15) * LDW;
-        f16x8 fb[KC][NTW][2];
-#pragma unroll
-        for (int kc = 0; kc < KC; ++kc)
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
-                    fb[kc][nt][pl] = *reinterpret_cast<const f16x8 *>(bb + (pl * COUT + nt * 16) * LDW + (c0 ^ (kc * 4)) * 8);
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            const f16x8 f0 = cd_cvt8(Acur[rt].x, Acur[rt].y), f1 = cd_cvt8(Acur[rt].z, Acur[rt].w);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, fb[0][nt][0], acc[rt][nt], 0, 0, 0);
-                acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, fb[0][nt][1], acc[rt][nt], 0, 0, 0);
-                acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, fb[1][nt][0], acc[rt][nt], 0, 0, 0);
-                acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, fb[1][nt][1], acc[rt][nt], 0, 0, 0);
-            }
-        }
-        storeW(b ^ 1);
-        __syncthreads();
-    };
-
-    int k = live ? (__ffs(live) - 1) : kvol, h = 0;
-    const int nunits = __popc(live) * NU;
-    loadW(k, h);
-    loadA(A0, k, h);
-    storeW(0);
-    __syncthreads();
-    for (int u = 0; u < nunits; u += 2) {
-        unit(A0, A1, 0, k, h);
-        unit(A1, A0, 1, k, h);
-    }
-
-    // ---- epilogue: this wave owns its columns for all 128 rows (D layout: col = lane&15, row = 4g + reg)
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const int o = wave * (16 * NTW) + nt * 16 + l15;
-        const float mul = a.out_mul[o];
-        const float bs = a.bias ? a.bias[o] : 0.f;
-        const float ps = a.post_scale ? a.post_scale[o] : 1.f;
-        const float pt = a.post_shift ? a.post_shift[o] : 0.f;
-        const float nsc = a.next_codes ? a.next_scale[o] : 0.f;
-        const int npos = cd_code_pos(o, COUT);
-        float mx = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = row0 + rt * 16 + 4 * g + r;
-                if (m < n) {
-                    float v = __fmul_rn(acc[rt][nt][r], mul);
-                    if (a.bias) v = __fadd_rn(v, bs);
-                    if (a.post_scale) v = __fadd_rn(__fmul_rn(v, ps), pt);
-                    if (a.residual) v = __fadd_rn(v, a.residual[(size_t)m * COUT + o]);
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (!a.skip_f32) a.feats_out[(size_t)m * COUT + o] = v;
-                    if (a.next_codes) a.next_codes[(size_t)m * COUT + npos] = cd_static_code(v, nsc, a.next_qmax);
-                    mx = fmaxf(mx, fabsf(v));
-                }
-            }
-        if (a.absmax_out) {
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            if (g == 0 && mx > a.absmax_out[o]) aq3d_atomic_max_pos(&a.absmax_out[o], mx);
+        for (int o = tid; o < CT; o += 256) {
+            const float mx = fmaxf(fmaxf(red[o], red[CT + o]), fmaxf(red[2 * CT + o], red[3 * CT + o]));
+            if (mx > a.absmax_out[ob + o]) aq3d_atomic_max_pos(&a.absmax_out[ob + o], mx);
         }
     }
 }
@@ -697,26 +523,15 @@ static int launch_cd(const SpCodedArgs &a, hipStream_t stream) {
     return AQ3D_OK;
 }
 
-template <int CIN, int COUT>
+template <int CIN, int COUT, int CT = COUT>
 static int launch_cw(const SpCodedArgs &a, hipStream_t stream) {
     constexpr int UC = CIN < 64 ? CIN : 64;
-    constexpr size_t lds = (size_t)4 * COUT * (UC == 64 ? UC : UC + 8) * 2 + (size_t)128 * 27 * 4 + (size_t)4 * COUT * 4 + 64;
-    const int grid = aq3d_div_up(a.cap_out, 128);
-    auto kern = spconv_cw_kernel<CIN, COUT>;
+    constexpr size_t lds = (size_t)4 * CT * (UC == 64 ? UC : UC + 8) * 2 + (size_t)128 * 27 * 4 + (size_t)4 * CT * 4 + 64;
+    const int grid = aq3d_div_up(aq3d_div_up(a.cap_out, 128), 8) * 8 * (COUT / CT);
+    auto kern = spconv_cw_kernel<CIN, COUT, CT>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid < 1 ? 1 : grid), dim3(256), lds, stream, a);
     AQ3D_CHECK_LAUNCH("aq3d_spconv_coded(wide)");
-    return AQ3D_OK;
-}
-
-template <int CIN, int COUT>
-static int launch_cw2(const SpCodedArgs &a, hipStream_t stream) {
-    constexpr size_t lds = (size_t)4 * COUT * 64 * 2 + (size_t)128 * 27 * 4 + 64;
-    const int grid = aq3d_div_up(a.cap_out, 128);
-    auto kern = spconv_cw2_kernel<CIN, COUT>;
-    if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid < 1 ? 1 : grid), dim3(256), lds, stream, a);
-    AQ3D_CHECK_LAUNCH("aq3d_spconv_coded(column split)");
     return AQ3D_OK;
 }
 
@@ -780,11 +595,16 @@ extern "C" int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void
     if (cin == 16 && cout == 32) return launch_cd<32, 27, 8>(a, stream);    // 58 KB of W' per workgroup: 8 waves share it
     if (cin == 32 && cout == 32) return launch_cw<32, 32>(a, stream);
     if (cin == 32 && cout == 64) return launch_cw<32, 64>(a, stream);
-    static const int variant = getenv("AQ3D_CW_VARIANT") ? atoi(getenv("AQ3D_CW_VARIANT")) : 2;   // TEMPORARY A/B switch (removed once measured)
-    if (variant == 2) {
-        if (cin == 64 && cout == 64) return launch_cw2<64, 64>(a, stream);
-        if (cin == 64 && cout == 128) return launch_cw2<64, 128>(a, stream);
-        if (cin == 128 && cout == 128) return launch_cw2<128, 128>(a, stream);
+    static const int ct = getenv("AQ3D_CW_CT") ? atoi(getenv("AQ3D_CW_CT")) : 64;   // TEMPORARY A/B switch (removed once measured)
+    if (ct == 32) {
+        if (cin == 64 && cout == 64) return launch_cw<64, 64, 32>(a, stream);
+        if (cin == 64 && cout == 128) return launch_cw<64, 128, 32>(a, stream);
+        if (cin == 128 && cout == 128) return launch_cw<128, 128, 32>(a, stream);
+    }
+    if (ct == 6432 && cin == 64 && cout == 64) return launch_cw<64, 64, 32>(a, stream);
+    if (ct == 64 || ct == 6432) {
+        if (cin == 64 && cout == 128) return launch_cw<64, 128, 64>(a, stream);
+        if (cin == 128 && cout == 128) return launch_cw<128, 128, 64>(a, stream);
     }
     if (cin == 64 && cout == 64) return launch_cw<64, 64>(a, stream);
     if (cin == 64 && cout == 128) return launch_cw<64, 128>(a, stream);
