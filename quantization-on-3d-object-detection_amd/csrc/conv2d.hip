@@ -16,6 +16,7 @@
 #include "common.h"
 #include "sq_layout.h"
 #include <stdio.h>
+#include <type_traits>
 #include <stdlib.h>
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -140,9 +141,12 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
         }
     }
 
-    f32x4 xr[PPT];
-    i32x4 wreg[WPT];
-    f32x4 sr, rr;
+    struct Stage {                  // registers of the K step in flight
+        f32x4 xr[PPT];
+        i32x4 wreg[WPT];
+        f32x4 sr, rr;
+    };
+    Stage stA;
     // every global read of the K loop is a bounded buffer load with a 32-bit byte offset: a tap that falls into the zero
     // padding is an out-of-range offset (returns zeros -> code 0), so there is no validity bookkeeping, no select of the
     // activation scale and no 64-bit address arithmetic per load (they were a third of the loop's VALU instructions)
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
         wrow_off[i] = min(oc0 + (item >> 2), a.Cout - 1) * K + (item & 3) * 16;
     }
 
-    auto load_step = [&](int kstep) {
+    auto load_step = [&](Stage &st, int kstep) {
         // K order: channel chunk outermost, the taps of one chunk back to back — the nine taps re-read the same fp32 pixels
         // (shifted by a pixel or a row), so their re-use distance is one step (16 KB per workgroup) instead of Cin/64 steps:
         // with tap-major order the 512-channel head conv fetched its input 8.6x from beyond L2. int32 sums: order-free.
@@ -165,32 +169,27 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
         const int kh = tap / a.ks, kw = tap - kh * a.ks;
         const int toff = (kh * a.W + kw) * a.in_ld + c0;      // wave-uniform
         const unsigned col = (unsigned)(tap * a.Cin + c0 + cq * 4) * 4u;
-        sr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, col, 0, 0));
-        rr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, col, 0, 0));
+        st.sr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, col, 0, 0));
+        st.rr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, col, 0, 0));
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const bool ok = (pmask[i] >> tap) & 1u;
             const unsigned off = ok ? (unsigned)(poff[i] + toff) * 4u : 0xfffffff0u;
-            xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0));
+            st.xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0));
         }
 #pragma unroll
         for (int i = 0; i < WPT; ++i)
-            wreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(wrow_off[i] + tap * a.Cin + c0), 0, 0));
+            st.wreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(wrow_off[i] + tap * a.Cin + c0), 0, 0));
     };
-    auto store_step = [&](int buf) {
-        if (clamp) {
+    auto store_step = [&](auto clamp_c, const Stage &st, int buf) {
+        constexpr bool CL = decltype(clamp_c)::value;
 #pragma unroll
-            for (int i = 0; i < PPT; ++i)
-                *reinterpret_cast<int *>(Xbuf(buf) + (pg + PGS * i) * LD + cq * 4) = quant_pack4<true>(xr[i], sr, rr, sx);
-        } else {
-#pragma unroll
-            for (int i = 0; i < PPT; ++i)
-                *reinterpret_cast<int *>(Xbuf(buf) + (pg + PGS * i) * LD + cq * 4) = quant_pack4<false>(xr[i], sr, rr, sx);
-        }
+        for (int i = 0; i < PPT; ++i)
+            *reinterpret_cast<int *>(Xbuf(buf) + (pg + PGS * i) * LD + cq * 4) = quant_pack4<CL>(st.xr[i], st.sr, st.rr, sx);
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int item = tid + NTH * i;
-            if (BM * 4 % NTH == 0 || item < BM * 4) *reinterpret_cast<i32x4 *>(Wbuf(buf) + (item >> 2) * LD + (item & 3) * 16) = wreg[i];
+            if (BM * 4 % NTH == 0 || item < BM * 4) *reinterpret_cast<i32x4 *>(Wbuf(buf) + (item >> 2) * LD + (item & 3) * 16) = st.wreg[i];
         }
     };
 
@@ -214,19 +213,28 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
             for (int j = 0; j < TJ; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
-    load_step(0);
-    store_step(0);
-    __syncthreads();
-    // branch-free steady state (the last step is peeled): conditionals around the loads / stores inside the loop made the
-    // compiler shuttle all accumulators between VGPRs and AGPRs every K step
-    for (int k = 0; k + 1 < nk; ++k) {
-        const int buf = k & 1;
-        load_step(k + 1);
-        mma_step(buf);
-        store_step(buf ^ 1);
+    // The whole K loop exists twice, with and without the clamp of calibrated (static) scales: a wave-uniform branch INSIDE the loop
+    // made the register allocator rotate the accumulators through other AGPRs every step (40 v_accvgpr_* per step on top of ~110
+    // useful VALU instructions, each waiting for the MFMA that produced its source).
+    auto k_loop = [&](auto clamp_c) {
+        load_step(stA, 0);
+        store_step(clamp_c, stA, 0);
         __syncthreads();
-    }
-    mma_step((nk - 1) & 1);
+        // branch-free steady state (the last step is peeled): conditionals around the loads / stores inside the loop made the
+        // compiler shuttle all accumulators between VGPRs and AGPRs every K step
+        for (int k = 0; k + 1 < nk; ++k) {
+            const int buf = k & 1;
+            load_step(stA, k + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            store_step(clamp_c, stA, buf ^ 1);
+            __syncthreads();
+        }
+        mma_step((nk - 1) & 1);
+    };
+    if (clamp) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
 
     // epilogue: lane holds oc = base + 4g .. 4g+3 for pixel column l15
     float mint[4] = {0.f, 0.f, 0.f, 0.f};
@@ -559,6 +567,8 @@ extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n,
     int bn = 128;
     if (aq3d_div_up(L, 128) * ocb * n < 512) bn = 64;
     if (aq3d_div_up(L, 64) * ocb * n < 512) bn = 32;
+    // (measured round 2, W150k: forcing 32-pixel tiles or 8 waves per workgroup on the 188 x 188 layers — more waves per SIMD — is
+    // 25-30 % SLOWER, and so is a two-step-deep load prefetch: per-workgroup fixed work and weight staging, not load latency, bound it)
     // pixel tiles are dealt to the 8 XCDs in contiguous ranges (grid x padded to a multiple of 8): vertically adjacent tiles of a
     // 3x3 conv re-read each other's input rows and then share an L2
     for (int i = 0; i < AQ3D_MAX_GROUP; ++i) grp.p[i].xcd_order = 1;
@@ -766,35 +776,101 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
     }
     mma_step((nk - 1) & 1);
 
+    // epilogue: a lane holds rows rbase .. rbase+3 of pixel column l15. With 4-aligned channel geometry the four rows are four
+    // consecutive output channels of ONE output pixel (deconv: row = (i*d + j) * Cout + oc, Cout % 4 == 0): one 16-byte store
+    // instead of four scalar ones, bias / BN loaded as vectors. (The deblocks write 36 MB each; the K loop has 4-8 steps, so the
+    // epilogue is a large part of the kernel.)
     const int d = a.deconv;
+    const bool vec4 = ((a.Cout | a.out_ld | a.out_coff | a.rows_total) & 3) == 0;      // wave-uniform
+    const int OW = d > 0 ? a.Wo * d : a.Wo, OH = d > 0 ? a.Ho * d : a.Ho;
+    int ph_[TJ], pw_[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int p = pix0 + wn * TJ * 16 + j * 16 + l15;
+        ph_[j] = p < L ? p / a.Wo : -1;
+        pw_[j] = p - ph_[j] * a.Wo;
+    }
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const int rbase = row0 + wm * TI * 16 + i * 16 + 4 * g;
+        if (vec4) {
+            if (rbase >= a.rows_total) continue;
+            const int ij = d > 0 ? rbase / a.Cout : 0;
+            const int oc = rbase - ij * a.Cout;
+            const int di = d > 0 ? ij / d : 0, dj = d > 0 ? ij - di * d : 0;
+            f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f}, ps = (f32x4){1.f, 1.f, 1.f, 1.f}, pt = b, om = ps;
+            if (SQ) om = *reinterpret_cast<const f32x4 *>(a.out_mul + oc);
+            if (a.bias) b = *reinterpret_cast<const f32x4 *>(a.bias + oc);
+            if (a.post_scale) {
+                ps = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
+                pt = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
+            }
+            float mint[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                if (ph_[j] < 0) continue;
+                const int oh = d > 0 ? ph_[j] * d + di : ph_[j], ow = d > 0 ? pw_[j] * d + dj : pw_[j];
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = __fadd_rn(acc[i][j][r], __fmul_rn(accl[i][j][r], 1.0f / 2048.f));
+                    if (SQ) t = __fmul_rn(t, om[r]);
+                    if (a.bias) t = __fadd_rn(t, b[r]);
+                    if (a.post_scale) t = __fadd_rn(__fmul_rn(t, ps[r]), pt[r]);
+                    if (a.relu) t = fmaxf(t, 0.f);
+                    v[r] = t;
+                }
+                *reinterpret_cast<f32x4 *>(a.y + ((size_t)oh * OW + ow) * a.out_ld + a.out_coff + oc) = v;
+                if (a.pieces_out) {
+                    if (a.pieces_mode == 1 && oh > 0 && oh < OH - 1 && ow > 0 && ow < OW - 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mint[r] = fmaxf(mint[r], fabsf(v[r]));   // interior: reduced in registers below
+                    } else {
+                        const int pc = piece_cls(oh, OH) * 4 + piece_cls(ow, OW);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            unsigned int *slot = &pm[pc * BM + (rbase - row0) + r];
+                            const unsigned int vb = __float_as_uint(fabsf(v[r]));
+                            if (vb > *slot) atomicMax(slot, vb);
+                        }
+                    }
+                }
+            }
+            if (a.pieces_out && a.pieces_mode == 1) {
+                // merged interior class (see conv2d_i8_kernel): max over the wave's 16 pixel lanes in registers, one LDS atomic per row
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float m = mint[r];
+                    m = fmaxf(m, __shfl_xor(m, 1, 64));
+                    m = fmaxf(m, __shfl_xor(m, 2, 64));
+                    m = fmaxf(m, __shfl_xor(m, 4, 64));
+                    m = fmaxf(m, __shfl_xor(m, 8, 64));
+                    if (l15 == 0 && m > 0.f) atomicMax(&pm[10 * BM + (rbase - row0) + r], __float_as_uint(m));
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
-            const int p = pix0 + wn * TJ * 16 + j * 16 + l15;
-            if (p >= L) continue;
+            if (ph_[j] < 0) continue;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rbase + r;
                 if (row >= a.rows_total) continue;
-                int oc = row;
-                size_t opix = (size_t)p;
-                if (d > 0) {  // row = (i*d + j)*Cout + oc ; input pixel p = (h, w) → output (h*d+i, w*d+j)
+                int oc = row, oh = ph_[j], ow = pw_[j];
+                if (d > 0) {  // row = (i*d + j)*Cout + oc ; input pixel (h, w) -> output (h*d+i, w*d+j)
                     const int ij = row / a.Cout;
                     oc = row - ij * a.Cout;
-                    const int h = p / a.Wo, w = p - h * a.Wo;
-                    opix = (size_t)(h * d + ij / d) * (a.Wo * d) + (w * d + ij % d);
+                    oh = ph_[j] * d + ij / d;
+                    ow = pw_[j] * d + ij % d;
                 }
                 float t = __fadd_rn(acc[i][j][r], __fmul_rn(accl[i][j][r], 1.0f / 2048.f));
                 if (SQ) t = __fmul_rn(t, a.out_mul[oc]);
                 if (a.bias) t = __fadd_rn(t, a.bias[oc]);
                 if (a.post_scale) t = __fadd_rn(__fmul_rn(t, a.post_scale[oc]), a.post_shift[oc]);
                 if (a.relu) t = fmaxf(t, 0.f);
-                a.y[opix * a.out_ld + a.out_coff + oc] = t;
+                a.y[((size_t)oh * OW + ow) * a.out_ld + a.out_coff + oc] = t;
                 if (a.pieces_out) {
-                    const int OW = d > 0 ? a.Wo * d : a.Wo, OH = d > 0 ? a.Ho * d : a.Ho;
-                    const int oh = (int)(opix / OW), ow = (int)(opix - (size_t)oh * OW);
                     unsigned int *slot = &pm[(piece_cls(oh, OH) * 4 + piece_cls(ow, OW)) * BM + (row - row0)];
                     const unsigned int vb = __float_as_uint(fabsf(t));
                     if (vb > *slot) atomicMax(slot, vb);
@@ -809,7 +885,12 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
             const int row = row0 + i % BM;
             if (v != 0u && row < a.rows_total) {
                 const int oc = d > 0 ? row % a.Cout : row;
-                atomicMax(reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)(i / BM) * a.pieces_ld + a.out_coff + oc, v);
+                int pc = i / BM;
+                if (a.pieces_mode == 1 && pc == 10) {       // spread the merged interior maximum over the four interior slots (L2 atomics on one address serialise)
+                    const int alt[4] = {10, 11, 14, 15};
+                    pc = alt[blockIdx.x & 3];
+                }
+                atomicMax(reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc * a.pieces_ld + a.out_coff + oc, v);
             }
         }
     }
@@ -822,6 +903,9 @@ static int prep_f32(ConvArgs *a, const aq3d_conv2d_problem *q, int *L_out) {
     AQ3D_REQUIRE(!q->pieces_out || q->pieces_ld >= g->out_coff + g->Cout, "aq3d_conv2d_f32: bad pieces_out layout");
     a->pieces_out = q->pieces_out;
     a->pieces_ld = q->pieces_ld;
+    a->pieces_mode = q->pieces_out ? q->pieces_mode : 0;
+    AQ3D_REQUIRE(a->pieces_mode == 0 || a->pieces_mode == 1, "aq3d_conv2d_f32: pieces_mode=%d", q->pieces_mode);
+    AQ3D_REQUIRE(a->pieces_mode == 0 || ((g->Cout | g->out_ld | g->out_coff) & 3) == 0, "aq3d_conv2d_f32: pieces_mode 1 needs 4-aligned channel geometry");
     AQ3D_REQUIRE(q->weight_or_params, "aq3d_conv2d_f32: null weight");
     AQ3D_REQUIRE((g->Cin & 15) == 0, "aq3d_conv2d_f32: Cin=%d must be a multiple of 16", g->Cin);
     a->w = q->weight_or_params;

@@ -14,7 +14,7 @@
 //   sp_prep_kernel      one launch per layer: blocks [0, row_blocks) quantise the producer's fp32 rows to codes, the rest
 //                       build W' (hi | lo planes) and the epilogue multipliers S * t_o. Both depend on the abs-max only.
 //   spconv_cd_kernel    Cin = 16, kvol = 27: whole W' resident in LDS, per-lane 8-byte gathers straight into MFMA registers.
-//   spconv_cw_kernel    Cin >= 32: 128 rows x all Cout per workgroup, W' streamed through double-buffered LDS in
+//   spconv_cw_kernel    Cin >= 32: 128 rows x CT (<= 64 at Cout = 128) output columns per workgroup, W' streamed through double-buffered LDS in
 //                       (kernel offset, 64-channel) units, A fragments gathered into registers (one 16-byte load per row and unit).
 // Code layout: rows of Cin bytes; for Cin >= 64 the bytes of every 64-channel group are permuted so that the 16 bytes a lane
 // loads are the 8 + 8 channels of its two MFMA K chunks: position 16g + 8kc + i  <->  channel 32kc + 8g + i.
@@ -595,19 +595,10 @@ extern "C" int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void
     if (cin == 16 && cout == 32) return launch_cd<32, 27, 8>(a, stream);    // 58 KB of W' per workgroup: 8 waves share it
     if (cin == 32 && cout == 32) return launch_cw<32, 32>(a, stream);
     if (cin == 32 && cout == 64) return launch_cw<32, 64>(a, stream);
-    static const int ct = getenv("AQ3D_CW_CT") ? atoi(getenv("AQ3D_CW_CT")) : 64;   // TEMPORARY A/B switch (removed once measured)
-    if (ct == 32) {
-        if (cin == 64 && cout == 64) return launch_cw<64, 64, 32>(a, stream);
-        if (cin == 64 && cout == 128) return launch_cw<64, 128, 32>(a, stream);
-        if (cin == 128 && cout == 128) return launch_cw<128, 128, 32>(a, stream);
-    }
-    if (ct == 6432 && cin == 64 && cout == 64) return launch_cw<64, 64, 32>(a, stream);
-    if (ct == 64 || ct == 6432) {
-        if (cin == 64 && cout == 128) return launch_cw<64, 128, 64>(a, stream);
-        if (cin == 128 && cout == 128) return launch_cw<128, 128, 64>(a, stream);
-    }
+    // Cout = 128: two 64-column blocks per row tile (measured on W150k, 35 k rows: 71 us against 98 us for one 128-column workgroup
+    // and 66 us for four 32-column ones, which lose whole-frame throughput to the 4x repeated gathers: 599 against 614 frames/s)
     if (cin == 64 && cout == 64) return launch_cw<64, 64>(a, stream);
-    if (cin == 64 && cout == 128) return launch_cw<64, 128>(a, stream);
-    if (cin == 128 && cout == 128) return launch_cw<128, 128>(a, stream);
+    if (cin == 64 && cout == 128) return launch_cw<64, 128, 64>(a, stream);
+    if (cin == 128 && cout == 128) return launch_cw<128, 128, 64>(a, stream);
     return AQ3D_ERR_UNSUPPORTED;
 }

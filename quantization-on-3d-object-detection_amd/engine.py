@@ -501,8 +501,10 @@ class Engine:
                             self._pieces_mode[pkey] = 1
                             rec["pieces_owner"] = False
                         elif fusable and all(p_["kind"] == "f32" for p_ in prods):
-                            for p_ in prods:        # fp32 producers (deblocks → bev_cat): exact classes, merged per workgroup in LDS
-                                p_["pieces_out"] = (self._pieces[pkey], cin, 0)
+                            for p_ in prods:        # fp32 producers (deblocks → bev_cat): merged per workgroup in LDS; interior classes
+                                p_["pieces_out"] = (self._pieces[pkey], cin, 1 if s == 1 else 0)    # merged for a stride-1 consumer
+                            if s == 1:
+                                self._pieces_mode[pkey] = 1
                             rec["pieces_owner"] = False
                     rec["pieces"] = self._pieces[pkey]
                     rec["params"] = torch.empty((ops.sq_param_bytes(cin, g.Cout, k),), dtype=torch.uint8, device=dev)
