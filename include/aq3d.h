@@ -148,7 +148,12 @@ enum {
     AQ3D_W_F32 = 0,    /* weight is f32 [kvol, Cout, Cin]                           */
     AQ3D_W_I8 = 1      /* weight is i8 codes [kvol, Cout, Cin]; value = code * w_dequant[cout] */
 };
-enum { AQ3D_FLAG_RELU = 1, AQ3D_FLAG_SKIP_F32 = 2 /* aq3d_spconv_coded with next_codes: do not store the fp32 rows */ };
+enum {
+    AQ3D_FLAG_RELU = 1,
+    AQ3D_FLAG_SKIP_F32 = 2, /* aq3d_spconv_coded with next_codes: do not store the fp32 rows */
+    AQ3D_FLAG_W_FP16 = 4    /* aq3d_spconv_coded: multiply by the hi plane of W' only (int8 codes x ONE fp16 weight, one MFMA per
+                               product: ~2^-12 relative error per weight, <= 1e-3 of the output scale per layer); default: hi | lo */
+};
 
 /*
  * Output-stationary gather-GEMM sparse convolution with fused epilogue (fp32 layers — conv_input, unquantised models — and
@@ -194,7 +199,8 @@ int aq3d_spconv_group(const aq3d_spconv_problem *problems, int32_t n, int32_t ac
  *   22 significant bits) + out_mul_out f32 [Cout] = S * w_dequant. weight_codes i8 [kvol, Cout, C]; bits <= 8.
  *   Either half may be skipped: x == NULL builds the weight copy only (static PTQ: once, the scales are constants),
  *   weight_codes == NULL quantises the rows only.
- * aq3d_spconv_coded: the gather-GEMM with the epilogue of aq3d_spconv (incl. next_scale / next_codes / AQ3D_FLAG_SKIP_F32). */
+ * aq3d_spconv_coded: the gather-GEMM with the epilogue of aq3d_spconv (incl. next_scale / next_codes / AQ3D_FLAG_SKIP_F32);
+ *   AQ3D_FLAG_W_FP16 selects the north star's "int8 weights x fp16 activations" product precision (see the flag). */
 int aq3d_spconv_coded_supported(int32_t cin, int32_t cout, int32_t kvol);
 size_t aq3d_spconv_wprep_bytes(int32_t cin, int32_t cout, int32_t kvol);
 int aq3d_spconv_prep(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C, int32_t bits,

@@ -135,9 +135,13 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
             const int ho = p / a.Wo;
             const int h0 = ho * a.stride - a.pad, w0 = (p - ho * a.Wo) * a.stride - a.pad;
             poff[i] = (h0 * a.W + w0) * a.in_ld + cq * 4;
+            unsigned hm = 0u, wm = 0u;              // rows / columns of the window inside the image; mask = their outer product
+            for (int k = 0; k < a.ks; ++k) {
+                hm |= (unsigned)((unsigned)(h0 + k) < (unsigned)a.H) << k;
+                wm |= (unsigned)((unsigned)(w0 + k) < (unsigned)a.W) << k;
+            }
             for (int kh = 0; kh < a.ks; ++kh)
-                for (int kw = 0; kw < a.ks; ++kw)
-                    if (h0 + kh >= 0 && h0 + kh < a.H && w0 + kw >= 0 && w0 + kw < a.W) pmask[i] |= 1u << (kh * a.ks + kw);
+                if ((hm >> kh) & 1u) pmask[i] |= wm << (kh * a.ks);
         }
     }
 

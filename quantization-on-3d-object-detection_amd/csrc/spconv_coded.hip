@@ -168,7 +168,7 @@ __device__ __forceinline__ signed char cd_static_code(float v, float scale, floa
 }
 
 // Cin = 16: K chunk = 2 kernel offsets x 16 channels; lane (l15, g) holds 8 channels of offset 2q + (g >> 1).
-template <int COUT, int KVOL, int NW>
+template <int COUT, int KVOL, int NW, int PL>
 __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
     constexpr int CIN = 16;
     constexpr int NTH = 64 * NW, TMW = 16 * NW;
@@ -178,8 +178,8 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
     constexpr int LD = NCH * 32 + 8;                     // halves per LDS weight row (16-byte pad)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16 *Bh = reinterpret_cast<_Float16 *>(smem_raw);          // [COUT][LD] hi, K index = offset * CIN + channel
-    _Float16 *Bl = Bh + COUT * LD;                                   // [COUT][LD] lo
-    float *red = reinterpret_cast<float *>(Bl + COUT * LD);          // [NW][COUT]
+    _Float16 *Bl = Bh + COUT * LD;                                   // [COUT][LD] lo (PL == 2 only)
+    float *red = reinterpret_cast<float *>(Bh + PL * COUT * LD);     // [NW][COUT]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
     const auto rsrc_f = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, (int)a.codes_bytes, 0x00020000);
     const auto rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, a.cap_out * KVOL * 4, 0x00020000);
 
-    for (int t = tid; t < 2 * COUT * (LD / 8); t += NTH) {
+    for (int t = tid; t < PL * COUT * (LD / 8); t += NTH) {
         const int pl = t / (COUT * (LD / 8)), r = t % (COUT * (LD / 8));
         const int o = r / (LD / 8), kk = (r % (LD / 8)) * 8;
         i32x4v v = (i32x4v){0, 0, 0, 0};
@@ -229,9 +229,11 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const f16x8 fh = *reinterpret_cast<const f16x8 *>(Bh + bofs + nt * 16 * LD + q * 32);
-                    const f16x8 fl = *reinterpret_cast<const f16x8 *>(Bl + bofs + nt * 16 * LD + q * 32);
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fh, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fl, acc[nt], 0, 0, 0);
+                    if (PL == 2) {
+                        const f16x8 fl = *reinterpret_cast<const f16x8 *>(Bl + bofs + nt * 16 * LD + q * 32);
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fl, acc[nt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -287,10 +289,9 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
 // slice go through LDS (double buffered, XOR-swizzled 128-byte rows as in the round-1 wide kernel), the A fragments of the
 // wave's two 16-row tiles are gathered straight into registers: ONE bounded buffer load per row and unit (16 bytes = the
 // 8 + 8 channels of the lane's two K chunks; 8 bytes when Cin = 32), missing neighbour = out-of-range offset = zeros.
-template <int CIN, int COUT, int CT>
+template <int CIN, int COUT, int CT, int RT, int FD, int PL>
 __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
     constexpr int NCB = COUT / CT;                      // column blocks: a workgroup computes CT of the COUT output channels
-    constexpr int RT = 2;
     constexpr int TM = 4 * RT * 16;
     constexpr int NT = CT / 16;
     constexpr int UC = CIN < 64 ? CIN : 64;
@@ -299,14 +300,13 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
     constexpr bool SWZ = UC == 64;
     constexpr int LDW = SWZ ? UC : UC + 8;              // halves per LDS weight row of one plane
     constexpr int PCH = CT * UC / 8;                  // 16-byte chunks of one plane of a unit
-    constexpr int WCH = 2 * PCH;
+    constexpr int WCH = PL * PCH;                        // PL = 2: hi | lo planes of W'; 1: the hi plane only (AQ3D_FLAG_W_FP16)
     constexpr int NWL = (WCH + 255) / 256;
     static_assert(CIN % 32 == 0 && CT % 16 == 0 && COUT % CT == 0, "channel granularity");
-    static_assert(WCH % 256 == 0, "whole chunk rounds");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16 *Wb = reinterpret_cast<_Float16 *>(smem_raw);              // [2 buffers][2 planes][CT][LDW]
-    int *nbr_s = reinterpret_cast<int *>(Wb + 4 * CT * LDW);          // [TM][kvol]
+    _Float16 *Wb = reinterpret_cast<_Float16 *>(smem_raw);              // [2 buffers][PL planes][CT][LDW]
+    int *nbr_s = reinterpret_cast<int *>(Wb + 2 * PL * CT * LDW);          // [TM][kvol]
     float *red = reinterpret_cast<float *>(nbr_s + TM * 27);            // [4][CT]
     int *mask_s = reinterpret_cast<int *>(red + 4 * CT);
 
@@ -362,7 +362,8 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
             const int pl = t / PCH, r = t % PCH;
             const int c8 = r % (UC / 8), o = r / (UC / 8);
             const unsigned off = (unsigned)((((k * COUT + ob + o) * 2 + pl) * CIN + h * UC + c8 * 8) * 2);
-            wn[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0);       // k = kvol is past the end of the tensor: zeros
+            if (WCH % 256 == 0 || t < WCH)
+                wn[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0);   // k = kvol is past the end of the tensor: zeros
         }
     };
     auto storeW = [&](int b) {
@@ -371,7 +372,8 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
             const int t = tid + 256 * i;
             const int pl = t / PCH, r = t % PCH;
             const int c8 = r % (UC / 8), o = r / (UC / 8);
-            *reinterpret_cast<i32x4v *>(Wb + ((b * 2 + pl) * CT + o) * LDW + (SWZ ? (c8 ^ ((o >> 1) & 7)) : c8) * 8) = wn[i];
+            if (WCH % 256 == 0 || t < WCH)
+                *reinterpret_cast<i32x4v *>(Wb + ((b * PL + pl) * CT + o) * LDW + (SWZ ? (c8 ^ ((o >> 1) & 7)) : c8) * 8) = wn[i];
         }
     };
     auto readSrc = [&](int (&src)[RT], int k) {
@@ -414,13 +416,13 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
             F[rt][0] = cd_cvt8(Acur[rt].x, Acur[rt].y);
             if (KC == 2) F[rt][KC - 1] = cd_cvt8(Acur[rt].z, Acur[rt].w);
         }
-        // fragment j = (kc * NT + nt) * 2 + plane: read FD ahead of the MFMAs that use it, each feeds RT MFMAs
-        constexpr int NF = KC * NT * 2;
-        constexpr int FD = 4;
+        // fragment j = (kc * NT + nt) * PL + plane: read FD ahead of the MFMAs that use it, each feeds RT MFMAs
+        constexpr int NF = KC * NT * PL;
+        constexpr int LA = NF - 1 < RT ? NF - 1 : RT;        // next unit's A loads issued inside the MFMA loop (the rest after it)
         const int c0 = SWZ ? (g ^ ((l15 >> 1) & 7)) : g;
-        const _Float16 *bb = Wb + (b * 2 * CT + l15) * LDW;
+        const _Float16 *bb = Wb + (b * PL * CT + l15) * LDW;
         auto frag = [&](int j) {
-            const int pl = j & 1, nt = (j >> 1) % NT, kc = (j >> 1) / NT;
+            const int pl = j % PL, nt = (j / PL) % NT, kc = (j / PL) / NT;
             const int c = SWZ ? (c0 ^ (kc * 4)) : (c0 + kc * 4);
             return *reinterpret_cast<const f16x8 *>(bb + (pl * CT + nt * 16) * LDW + c * 8);
         };
@@ -433,14 +435,16 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             if (j + FD < NF) fb[(j + FD) % (FD + 1)] = frag(j + FD);
-            if (j >= 1 && j <= RT) loadA1(Anext, src, h, j - 1);
+            if (j >= 1 && j <= LA) loadA1(Anext, src, h, j - 1);
             __builtin_amdgcn_sched_barrier(0);
-            const int nt = (j >> 1) % NT, kc = (j >> 1) / NT;
+            const int nt = (j / PL) % NT, kc = (j / PL) / NT;
             const f16x8 f = fb[j % (FD + 1)];
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F[rt][kc], f, acc[rt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int rt = LA; rt < RT; ++rt) loadA1(Anext, src, h, rt);
         storeW(b ^ 1);
         __syncthreads();
     };
@@ -510,25 +514,28 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
 }
 
 // ------------------------------------------------------------------ host side
-template <int COUT, int KVOL, int NW>
+template <int COUT, int KVOL, int NW, int PL>
 static int launch_cd(const SpCodedArgs &a, hipStream_t stream) {
     constexpr int NCH = (KVOL * 16 + 31) / 32;
-    constexpr size_t lds = (size_t)2 * COUT * (NCH * 32 + 8) * 2 + NW * COUT * 4;
+    constexpr size_t lds = (size_t)PL * COUT * (NCH * 32 + 8) * 2 + NW * COUT * 4;
     const int tiles = aq3d_div_up(a.cap_out, 16 * NW);
     const int grid = tiles < 2048 ? (tiles < 1 ? 1 : tiles) : 2048;
-    auto kern = spconv_cd_kernel<COUT, KVOL, NW>;
+    auto kern = spconv_cd_kernel<COUT, KVOL, NW, PL>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
     AQ3D_CHECK_LAUNCH("aq3d_spconv_coded(direct)");
     return AQ3D_OK;
 }
 
-template <int CIN, int COUT, int CT = COUT>
+template <int CIN, int COUT, int CT, int PL>
 static int launch_cw(const SpCodedArgs &a, hipStream_t stream) {
+    // 2 row tiles per wave (RT), fragments read 4 ahead (FD): measured round 2 against RT = 1 / 4 and FD = 8 (all slower)
+    constexpr int RT = 2, FD = 4;
     constexpr int UC = CIN < 64 ? CIN : 64;
-    constexpr size_t lds = (size_t)4 * CT * (UC == 64 ? UC : UC + 8) * 2 + (size_t)128 * 27 * 4 + (size_t)4 * CT * 4 + 64;
-    const int grid = aq3d_div_up(aq3d_div_up(a.cap_out, 128), 8) * 8 * (COUT / CT);
-    auto kern = spconv_cw_kernel<CIN, COUT, CT>;
+    constexpr int TM = 64 * RT;
+    constexpr size_t lds = (size_t)2 * PL * CT * (UC == 64 ? UC : UC + 8) * 2 + (size_t)TM * 27 * 4 + (size_t)4 * CT * 4 + 64;
+    const int grid = aq3d_div_up(aq3d_div_up(a.cap_out, TM), 8) * 8 * (COUT / CT);
+    auto kern = spconv_cw_kernel<CIN, COUT, CT, RT, FD, PL>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid < 1 ? 1 : grid), dim3(256), lds, stream, a);
     AQ3D_CHECK_LAUNCH("aq3d_spconv_coded(wide)");
@@ -591,14 +598,20 @@ extern "C" int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void
     AQ3D_REQUIRE(!(flags & AQ3D_FLAG_SKIP_F32) || next_codes, "aq3d_spconv_coded: AQ3D_FLAG_SKIP_F32 without next_codes would discard the output");
     a.next_scale = next_scale; a.next_codes = next_codes; a.next_qmax = next_codes ? (float)((1 << (next_bits - 1)) - 1) : 0.f;
     a.skip_f32 = (flags & AQ3D_FLAG_SKIP_F32) ? 1 : 0;
-    if (cin == 16 && cout == 16) return launch_cd<16, 27, 4>(a, stream);
-    if (cin == 16 && cout == 32) return launch_cd<32, 27, 8>(a, stream);    // 58 KB of W' per workgroup: 8 waves share it
-    if (cin == 32 && cout == 32) return launch_cw<32, 32>(a, stream);
-    if (cin == 32 && cout == 64) return launch_cw<32, 64>(a, stream);
     // Cout = 128: two 64-column blocks per row tile (measured on W150k, 35 k rows: 71 us against 98 us for one 128-column workgroup
     // and 66 us for four 32-column ones, which lose whole-frame throughput to the 4x repeated gathers: 599 against 614 frames/s)
-    if (cin == 64 && cout == 64) return launch_cw<64, 64>(a, stream);
-    if (cin == 64 && cout == 128) return launch_cw<64, 128, 64>(a, stream);
-    if (cin == 128 && cout == 128) return launch_cw<128, 128, 64>(a, stream);
+#define AQ3D_CODED_DISPATCH(PL_) \
+    do { \
+        if (cin == 16 && cout == 16) return launch_cd<16, 27, 4, PL_>(a, stream); \
+        if (cin == 16 && cout == 32) return launch_cd<32, 27, 8, PL_>(a, stream);    /* 58 KB of W' per workgroup: 8 waves share it */ \
+        if (cin == 32 && cout == 32) return launch_cw<32, 32, 32, PL_>(a, stream); \
+        if (cin == 32 && cout == 64) return launch_cw<32, 64, 64, PL_>(a, stream); \
+        if (cin == 64 && cout == 64) return launch_cw<64, 64, 64, PL_>(a, stream); \
+        if (cin == 64 && cout == 128) return launch_cw<64, 128, 64, PL_>(a, stream); \
+        if (cin == 128 && cout == 128) return launch_cw<128, 128, 64, PL_>(a, stream); \
+    } while (0)
+    if (flags & AQ3D_FLAG_W_FP16) AQ3D_CODED_DISPATCH(1);
+    AQ3D_CODED_DISPATCH(2);
+#undef AQ3D_CODED_DISPATCH
     return AQ3D_ERR_UNSUPPORTED;
 }

@@ -45,6 +45,11 @@ class Detector3DTemplate(nn.Module):
         self.max_batch_size = 1          # engine buffers are sized for this many frames per forward
         self.voxel_capacity = None       # rows of the sparse buffers (default MAX_NUMBER_OF_VOXELS * max_batch_size)
         self.voxelize_on_device = True   # False: consume batch_dict['voxels'/'voxel_coords'] when present
+        # quantised sparse convs: False = weights as an fp16 hi|lo pair (two MFMAs per product, fp32-grade sums, every layer within
+        # 2e-5 of the oracle); True = ONE fp16 weight per product (the north star's "int8 weights x fp16 activations" precision:
+        # ~2^-12 per weight, layers within 1e-3 of their output scale, half the matrix work). Set before the first forward
+        # (or call invalidate_engine()).
+        self.sparse_fp16_weights = False
 
     @property
     def mode(self):

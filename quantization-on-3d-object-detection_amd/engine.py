@@ -136,6 +136,7 @@ class Engine:
         self.steps = []
         self.tensors = {}
         self._voxel_ws = None
+        self.sparse_fp16_weights = bool(getattr(det, "sparse_fp16_weights", False))
         self._force_rows = False     # teacher-forced tests: run the rows-only quantiser even where a producer epilogue does it
         if isinstance(det.backbone_3d, VoxelResBackBone8xVoxelNeXt):
             self.fully_sparse = True
@@ -923,7 +924,8 @@ class Engine:
                                      residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
                                      absmax_out=self.arena.view(out["amax"]), out=out["buf"],
                                      next_scale=None if nx is None else nx["scale"], next_codes=None if nx is None else nx["codes"],
-                                     next_bits=8 if nx is None else nx["bits"], skip_f32=bool(rec.get("skip_f32")))
+                                     next_bits=8 if nx is None else nx["bits"], skip_f32=bool(rec.get("skip_f32")),
+                                     fp16_weights=self.sparse_fp16_weights)
                 return
             L = ops._lib.load()
             with _Timed(self, "quantize_rows"):

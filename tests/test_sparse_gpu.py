@@ -234,3 +234,10 @@ def test_spconv_coded_vs_oracle(dev, cin, cout, ksize, per_tensor):
     y = ops.spconv_coded(codes, wprep, out_mul, nbr, count, absmax_out=am, **kw)[:m].cpu().numpy()
     assert np.abs(y - ref).max() <= tol, np.abs(y - ref).max() / max(1.0, np.abs(ref).max())
     np.testing.assert_array_equal(am.cpu().numpy(), np.abs(y).max(axis=0))
+    # AQ3D_FLAG_W_FP16 (north star: "int8 weights x fp16 activations"): ONE fp16 weight per product, ~2^-12 relative per weight.
+    # Bar: 1e-3 of the output scale; typically 1e-4
+    am16 = torch.zeros((cout,), device=dev)
+    y16 = ops.spconv_coded(codes, wprep, out_mul, nbr, count, absmax_out=am16, fp16_weights=True, **kw)[:m].cpu().numpy()
+    err16 = np.abs(y16 - ref).max() / max(1.0, np.abs(ref).max())
+    assert err16 <= 1e-3, err16
+    np.testing.assert_array_equal(am16.cpu().numpy(), np.abs(y16).max(axis=0))
