@@ -76,6 +76,14 @@ def main():
     from oracle import sparse as OS
     dev = torch.device("cuda:0")
     shape = [41, 1504, 1504]
+    # bring the GPU out of its idle clocks once (the first timing of a fresh process otherwise runs on the ramp: the 1 922 us
+    # outlier of the round-1 sweep, and a 30 us "16-channel" line in round 2's first sweeps)
+    junk = torch.empty((64 << 20,), dtype=torch.float32, device=dev)
+    t_end = time.time() + 0.7
+    while time.time() < t_end:
+        junk.mul_(1.0001)
+        torch.cuda.synchronize()
+    del junk
     for m_req in args.voxels:
         idx = occupancy(args.occupancy, m_req, order=args.order)
         m = len(idx)

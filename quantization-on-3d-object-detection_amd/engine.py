@@ -169,7 +169,7 @@ class Engine:
         # second HIP stream for the index (rulebook) chain, see _run_steps; AQ3D_INDEX_STREAM=0 keeps everything on one stream
         self.index_stream = None
         if device.type == "cuda" and os.environ.get("AQ3D_INDEX_STREAM", "1") != "0" and not self.split_index:
-            self.index_stream = torch.cuda.Stream(device=device)
+            self.index_stream = det._next_stream(device) if hasattr(det, "_next_stream") else torch.cuda.Stream(device=device)
             self._ev_main = torch.cuda.Event()
             self._ev_idx = [torch.cuda.Event() for _ in range(16)]
 
@@ -997,8 +997,16 @@ class Engine:
         if wq_._if_calib:
             wq_.collect(amax_w)
 
-    def _decode_nms(self, B):
+    def _for_each_head(self, body):
+        """The decode -> NMS -> gather chains of the heads, one after the other on the frame's stream. (Round 2 tried forked side
+        streams, which a captured hipGraph keeps as parallel branches: VoxelNeXt's 6 chains then overlap — p10 latency 4.15 -> 3.63 ms
+        — but throughput with two plans in flight fell from 297 to 176 frames/s: the graph's internal branch streams compete with
+        the other plan for the hardware queues. Batching the heads inside the kernels is the way, not done yet.)"""
         for hi, h in enumerate(self.heads):
+            body(hi, h)
+
+    def _decode_nms(self, B):
+        def body(hi, h):
             s = h["slots"]
             for b in range(B):
                 buf = h["buf"][b].view(-1, self.HEAD_LD)
@@ -1012,6 +1020,7 @@ class Engine:
                 ops.gather_dets(h["cand_boxes"][b][:cap_nms], h["cand_scores"][b][:cap_nms], h["cand_labels"][b][:cap_nms],
                                 h["class_map"], h["keep"][b][:cap_nms], self.det_counts[self.slot, b, hi:hi + 1],
                                 out=(h["out_boxes"][self.slot, b][:cap_nms], h["out_scores"][self.slot, b][:cap_nms], h["out_labels"][self.slot, b][:cap_nms]))
+        self._for_each_head(body)
 
     def run_head_from(self, bev_nhwc):
         """Run only shared conv → head branches → decode → NMS on given BEV features [B, H, W, C] (parity tests feed
@@ -1238,7 +1247,8 @@ class Engine:
 
     def _voxel_decode_nms(self):
         b = 0
-        for hi, h in enumerate(self.heads):
+
+        def body(hi, h):
             lv = self.levels[h["level"]]
             o = h["outs"]
             ops.voxel_decode(o["hm"]["buf"], o["center"]["buf"], o["center_z"]["buf"], o["dim"]["buf"], o["rot"]["buf"],
@@ -1250,6 +1260,7 @@ class Engine:
             ops.gather_dets(h["cand_boxes"][b][:cap_nms], h["cand_scores"][b][:cap_nms], h["cand_labels"][b][:cap_nms],
                             h["class_map"], h["keep"][b][:cap_nms], self.det_counts[self.slot, b, hi:hi + 1],
                             out=(h["out_boxes"][self.slot, b][:cap_nms], h["out_scores"][self.slot, b][:cap_nms], h["out_labels"][self.slot, b][:cap_nms]))
+        self._for_each_head(body)
 
     def _index_down(self, li):
         lv_out = self.levels[li]
