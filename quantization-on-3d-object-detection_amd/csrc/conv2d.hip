@@ -571,6 +571,8 @@ extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n,
     int bn = 128;
     if (aq3d_div_up(L, 128) * ocb * n < 512) bn = 64;
     if (aq3d_div_up(L, 64) * ocb * n < 512) bn = 32;
+    // (also measured: the per-column scales s | 1/s staged once per workgroup in LDS instead of two global loads per thread and step —
+    // 2K floats of dynamic LDS cost more occupancy than the loads: Cin = 256: 50 -> 73 us, Cin = 512: 71 -> 101 us, Cin = 128 unchanged)
     // (measured round 2, W150k: forcing 32-pixel tiles or 8 waves per workgroup on the 188 x 188 layers — more waves per SIMD — is
     // 25-30 % SLOWER, and so is a two-step-deep load prefetch: per-workgroup fixed work and weight staging, not load latency, bound it)
     // pixel tiles are dealt to the 8 XCDs in contiguous ranges (grid x padded to a multiple of 8): vertically adjacent tiles of a
