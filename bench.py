@@ -203,16 +203,21 @@ def cpu_baseline(cfg, ds, state, frames=2, warm=1, threads=None):
     else:
         from oracle import centerpoint as OC
         run, name = (lambda p: OC.run(state, cfg, p, OC.Recipe(8, 8, True, 0.5))), "oracle.centerpoint.run"
-    times, nb = [], 0
+    times, nb, cpu_s = [], 0, 0.0
     for i in range(warm + frames):
         pts = ds[i % len(ds)]["points"]
-        t0 = time.time()
+        t0, c0 = time.time(), time.process_time()
         b, s, l = run(pts)
         if i >= warm:
             times.append(time.time() - t0)
+            cpu_s += time.process_time() - c0
             nb = len(s)
     med = float(np.median(times))
-    return {"value": 1.0 / med, "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+    # `cores` = the cores the port actually kept busy (process CPU time / wall time): the oracle is numpy gather loops around a few
+    # BLAS calls, so the configured thread count says little (profiles/r02/cpu_baseline_protocol.json: 12.1 s at T = 128, 11.9 s at T = 1)
+    busy = cpu_s / max(sum(times), 1e-9)
+    return {"value": 1.0 / med, "unit": "frames/s", "cores": max(1, int(round(busy))), "threads_configured": int(torch.get_num_threads()),
+            "cores_busy_avg": round(busy, 2), "kind": "port",
             "sample": "%d warm-up + %d timed frames (%d pts) through %s, median %.1f s/frame (all: %s), %d boxes in the last one"
                       % (warm, frames, len(pts), name, med, ", ".join("%.1f" % t for t in times), nb)}
 

@@ -355,6 +355,30 @@ int aq3d_gather_dets(const float *boxes, int32_t box_ld, const float *scores, co
                      const int32_t *class_map, const int32_t *keep, const int32_t *keep_count, int32_t cap,
                      float *boxes_out, float *scores_out, int64_t *labels_out, void *stream);
 
+/* The whole post-processing chain of up to 8 heads in FIVE launches (top-K, decode, mask, sweep, gather) instead of five per head:
+ * center_head.py:297-365 (generate_predicted_boxes: every head in turn) and voxelnext_head.py:418-560. Per head the arguments of
+ * aq3d_center_decode (coords == NULL) or aq3d_voxel_decode (coords / count / cap given), of aq3d_nms_rotated on the first nms_cap
+ * (<= cfg->K) candidates, and of aq3d_gather_dets; results identical to the three calls head by head. */
+typedef struct aq3d_head_problem {
+    const float *hm, *center, *center_z, *dim, *rot, *vel;     /* maps (dense head) or rows (sparse head) */
+    const int32_t *coords, *count;                             /* sparse head only                         */
+    int32_t cap;                                               /* sparse head: capacity of the rows        */
+    const aq3d_decode_cfg *cfg;
+    float *cand_boxes, *cand_scores;                           /* [K, 7 or 9], [K]                          */
+    int32_t *cand_labels, *cand_count;                         /* [K], [1]                                  */
+    void *decode_workspace;
+    size_t decode_workspace_bytes;                             /* aq3d_center_decode_workspace_bytes(cfg)   */
+    float nms_thresh;
+    int32_t nms_cap, post_max;
+    int32_t *keep, *keep_count;                                /* [nms_cap], [1]                            */
+    void *nms_workspace;
+    size_t nms_workspace_bytes;                                /* aq3d_nms_workspace_bytes(nms_cap)         */
+    const int32_t *class_map;                                  /* head-local class -> global class, or NULL */
+    float *boxes_out, *scores_out;                             /* [nms_cap, 7 or 9], [nms_cap]              */
+    int64_t *labels_out;                                       /* [nms_cap]                                 */
+} aq3d_head_problem;
+int aq3d_decode_nms_batch(const aq3d_head_problem *heads, int32_t n, void *stream);
+
 /* ---------------------------------------------------------------- VoxelNeXt (fully sparse) extras ---------------- */
 
 size_t aq3d_bev_merge_workspace_bytes(int32_t n_levels, int32_t cap_in, int32_t out_table_size);

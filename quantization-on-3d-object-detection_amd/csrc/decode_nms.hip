@@ -119,9 +119,13 @@ __device__ __forceinline__ float sigmoidf_dev(float x) { return __fdiv_rn(1.0f, 
 // ------------------------------------------------------------------ stage 1: per-class top-K (radix select + sort)
 // grid = num_classes, block = 1024. Writes K composite keys (score bits << 32 | ~index) per class, sorted descending;
 // slots beyond the number of pixels hold 0.
-__global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__restrict__ hm, int hm_ld, int L_static,
-                                                              const int *__restrict__ count, int K, int Kpad,
-                                                              int cache_keys, float score_thresh, u64 *__restrict__ out) {
+// Every stage takes up to AQ3D_MAX_HEADS independent problems per launch (blockIdx.y / .z = head): the decode -> NMS -> gather
+// chain of a head is a string of single-workgroup, latency-bound launches (~170 us per head), and the 6-head models (nuScenes
+// CenterPoint, VoxelNeXt) ran it six times back to back.
+#define AQ3D_MAX_HEADS 8
+__device__ __forceinline__ void topk_per_class_body(const float *__restrict__ hm, int hm_ld, int L_static,
+                                                    const int *__restrict__ count, int K, int Kpad,
+                                                    int cache_keys, float score_thresh, u64 *__restrict__ out, const int cls) {
     int L = L_static;            // dense map: H*W pixels; sparse head: the live rows (device count, capped by L_static)
     if (count) { L = *count; if (L > L_static) L = L_static; if (L < 0) L = 0; }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -133,7 +137,6 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
     __shared__ unsigned int s_prefix;
     __shared__ int s_remaining, s_fill, s_ties;
     __shared__ unsigned int tie_idx[TIE_CAP];
-    const int cls = blockIdx.x;
     const float *col = hm + cls;
     auto key_of = [&](int i) -> unsigned int {
         return cache_keys ? keys_s[i] : __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
@@ -310,6 +313,23 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(const float *__res
     for (int i = threadIdx.x; i < K; i += blockDim.x) out[(size_t)cls * K + i] = (i < Keff) ? sel[i] : 0ull;
 }
 
+struct TopkArgs {
+    const float *hm;
+    int hm_ld, L_static;
+    const int *count;
+    int K, Kpad, cache_keys, nclass;
+    float score_thresh;
+    u64 *out;
+};
+struct TopkBatch {
+    TopkArgs p[AQ3D_MAX_HEADS];
+};
+__global__ __launch_bounds__(1024) void topk_per_class_kernel(TopkBatch b) {
+    const TopkArgs &a = b.p[blockIdx.y];
+    if ((int)blockIdx.x >= a.nclass) return;
+    topk_per_class_body(a.hm, a.hm_ld, a.L_static, a.count, a.K, a.Kpad, a.cache_keys, a.score_thresh, a.out, (int)blockIdx.x);
+}
+
 // ------------------------------------------------------------------ stage 2: top-K over classes*K, decode, mask
 struct DecodeParams {
     aq3d_decode_cfg c;
@@ -317,9 +337,9 @@ struct DecodeParams {
     const int *coords;      // sparse head: rows (b, z|0, y, x) of the voxels; NULL for a dense map
 };
 
-__global__ __launch_bounds__(1024) void decode_kernel(const u64 *__restrict__ cand, int ncand, int Npad, DecodeParams q,
-                                                      float *__restrict__ boxes_out, float *__restrict__ scores_out,
-                                                      int *__restrict__ labels_out, int *__restrict__ count_out) {
+__device__ __forceinline__ void decode_body(const u64 *__restrict__ cand, int ncand, int Npad, const DecodeParams &q,
+                                            float *__restrict__ boxes_out, float *__restrict__ scores_out,
+                                            int *__restrict__ labels_out, int *__restrict__ count_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *keys = reinterpret_cast<u64 *>(smem_raw);  // [Npad] : score bits << 32 | ~position (position = class*K + rank)
     __shared__ int sh[16];
@@ -384,6 +404,21 @@ __global__ __launch_bounds__(1024) void decode_kernel(const u64 *__restrict__ ca
     if (threadIdx.x == 0) *count_out = total;
 }
 
+struct DecodeArgs {
+    const u64 *cand;
+    int ncand, Npad;
+    DecodeParams q;
+    float *boxes_out, *scores_out;
+    int *labels_out, *count_out;
+};
+struct DecodeBatch {
+    DecodeArgs p[AQ3D_MAX_HEADS];
+};
+__global__ __launch_bounds__(1024) void decode_kernel(DecodeBatch b) {
+    const DecodeArgs &a = b.p[blockIdx.x];
+    decode_body(a.cand, a.ncand, a.Npad, a.q, a.boxes_out, a.scores_out, a.labels_out, a.count_out);
+}
+
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 extern "C" size_t aq3d_center_decode_workspace_bytes(const aq3d_decode_cfg *cfg) {
@@ -391,42 +426,79 @@ extern "C" size_t aq3d_center_decode_workspace_bytes(const aq3d_decode_cfg *cfg)
     return (size_t)cfg->num_classes * cfg->K * sizeof(u64) + 256;
 }
 
+// One decode problem: dense maps (coords == NULL: aq3d_center_decode) or rows of a sparse head (aq3d_voxel_decode).
+struct DecodeProblem {
+    const float *hm, *center, *center_z, *dim, *rot, *vel;
+    const int32_t *coords, *count;
+    int32_t cap;
+    const aq3d_decode_cfg *cfg;
+    float *boxes_out, *scores_out;
+    int32_t *labels_out, *count_out;
+    void *workspace;
+    size_t workspace_bytes;
+};
+
+static int check_decode(const DecodeProblem &d, const char *who) {
+    AQ3D_REQUIRE(d.hm && d.center && d.center_z && d.dim && d.rot && d.cfg && d.boxes_out && d.scores_out && d.labels_out && d.count_out &&
+                     d.workspace, "%s: null argument", who);
+    AQ3D_REQUIRE(!d.cfg->has_vel || d.vel, "%s: has_vel without vel", who);
+    AQ3D_REQUIRE(d.cfg->num_classes >= 1 && d.cfg->num_classes <= 16, "%s: num_classes=%d", who, d.cfg->num_classes);
+    AQ3D_REQUIRE(d.cfg->K >= 1 && d.cfg->K <= 512, "%s: K=%d not in 1..512", who, d.cfg->K);
+    if (d.coords) AQ3D_REQUIRE(d.count && d.cap >= 1, "%s: sparse head without count / cap=%d", who, d.cap);
+    else AQ3D_REQUIRE(d.cfg->H > 0 && d.cfg->W > 0, "%s: empty map", who);
+    if (d.workspace_bytes < aq3d_center_decode_workspace_bytes(d.cfg)) {
+        aq3d_set_error("%s: workspace too small", who);
+        return AQ3D_ERR_WORKSPACE;
+    }
+    return AQ3D_OK;
+}
+
+// top-K per class + decode of n <= AQ3D_MAX_HEADS checked problems: two launches
+static void launch_decode(const DecodeProblem *d, int n, hipStream_t stream) {
+    TopkBatch tb;
+    DecodeBatch db;
+    size_t lds1_max = 0, lds2_max = 0;
+    int max_classes = 1;
+    for (int i = 0; i < n; ++i) {
+        const aq3d_decode_cfg *cfg = d[i].cfg;
+        const int L = d[i].coords ? d[i].cap : cfg->H * cfg->W, K = cfg->K, Kpad = next_pow2(K);
+        size_t lds1 = (size_t)Kpad * 8 + 256 * 4 + 16 * 4;
+        // key cache [L] — or, in the pre-filtered mode, keys + pixel indices of up to 16384 candidates (2 x 64 KiB); the
+        // order-preserving score-threshold pre-filter is always on (identical detections)
+        const size_t key_bytes = (size_t)L * 4 > 131072 ? (size_t)L * 4 : 131072;
+        const int cache_keys = (lds1 + key_bytes <= 150 * 1024) ? 1 : 0;   // one workgroup may use up to 160 KiB of LDS
+        if (cache_keys) lds1 += key_bytes;
+        TopkArgs &t = tb.p[i];
+        t.hm = d[i].hm; t.hm_ld = cfg->hm_ld; t.L_static = L; t.count = d[i].coords ? d[i].count : nullptr; t.K = K; t.Kpad = Kpad;
+        t.cache_keys = cache_keys; t.nclass = cfg->num_classes; t.score_thresh = cfg->score_thresh; t.out = (u64 *)d[i].workspace;
+        DecodeArgs &a = db.p[i];
+        a.cand = (const u64 *)d[i].workspace; a.ncand = cfg->num_classes * K; a.Npad = next_pow2(a.ncand);
+        a.q.c = *cfg; a.q.center = d[i].center; a.q.center_z = d[i].center_z; a.q.dim = d[i].dim; a.q.rot = d[i].rot; a.q.vel = d[i].vel;
+        a.q.coords = d[i].coords;
+        a.boxes_out = d[i].boxes_out; a.scores_out = d[i].scores_out; a.labels_out = d[i].labels_out; a.count_out = d[i].count_out;
+        lds1_max = lds1 > lds1_max ? lds1 : lds1_max;
+        const size_t lds2 = (size_t)a.Npad * 8;
+        lds2_max = lds2 > lds2_max ? lds2 : lds2_max;
+        max_classes = cfg->num_classes > max_classes ? cfg->num_classes : max_classes;
+    }
+    for (int i = n; i < AQ3D_MAX_HEADS; ++i) { tb.p[i] = tb.p[0]; db.p[i] = db.p[0]; }
+    if (lds1_max > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(topk_per_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1_max);
+    hipLaunchKernelGGL(topk_per_class_kernel, dim3(max_classes, n), dim3(1024), lds1_max, stream, tb);
+    if (lds2_max > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2_max);
+    hipLaunchKernelGGL(decode_kernel, dim3(n), dim3(1024), lds2_max, stream, db);
+}
+
 extern "C" int aq3d_center_decode(const float *hm, const float *center, const float *center_z, const float *dim,
                                   const float *rot, const float *vel, const aq3d_decode_cfg *cfg, float *boxes_out,
                                   float *scores_out, int32_t *labels_out, int32_t *count_out, void *workspace,
                                   size_t workspace_bytes, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    AQ3D_REQUIRE(hm && center && center_z && dim && rot && cfg && boxes_out && scores_out && labels_out && count_out && workspace,
-                 "aq3d_center_decode: null argument");
-    AQ3D_REQUIRE(!cfg->has_vel || vel, "aq3d_center_decode: has_vel without vel map");
-    AQ3D_REQUIRE(cfg->num_classes >= 1 && cfg->num_classes <= 16, "aq3d_center_decode: num_classes=%d", cfg->num_classes);
-    AQ3D_REQUIRE(cfg->K >= 1 && cfg->K <= 512, "aq3d_center_decode: K=%d not in 1..512", cfg->K);
-    AQ3D_REQUIRE(cfg->H > 0 && cfg->W > 0, "aq3d_center_decode: empty map");
-    if (workspace_bytes < aq3d_center_decode_workspace_bytes(cfg)) {
-        aq3d_set_error("aq3d_center_decode: workspace too small");
-        return AQ3D_ERR_WORKSPACE;
-    }
-    const int L = cfg->H * cfg->W, K = cfg->K;
-    const int Kpad = next_pow2(K);
-    u64 *cand = (u64 *)workspace;
-    size_t lds1 = (size_t)Kpad * 8 + 256 * 4 + 16 * 4;
-    const bool no_filter = false;     // the order-preserving score-threshold pre-filter is always on (identical detections)
-    // key cache [L] — or, in the pre-filtered mode, keys + pixel indices of up to 16384 candidates (2 x 64 KiB)
-    const size_t key_bytes = (size_t)L * 4 > 131072 ? (size_t)L * 4 : 131072;
-    const int cache_keys = (lds1 + key_bytes <= 150 * 1024) ? 1 : 0;   // one workgroup may use up to 160 KiB of LDS
-    if (cache_keys) lds1 += key_bytes;
-    if (lds1 > 64 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(topk_per_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipLaunchKernelGGL(topk_per_class_kernel, dim3(cfg->num_classes), dim3(1024), lds1, stream, hm, cfg->hm_ld, L, (const int *)nullptr,
-                       K, Kpad, cache_keys, no_filter ? -1.f : cfg->score_thresh, cand);
-    const int ncand = cfg->num_classes * K;
-    const int Npad = next_pow2(ncand);
-    DecodeParams q;
-    q.c = *cfg; q.center = center; q.center_z = center_z; q.dim = dim; q.rot = rot; q.vel = vel; q.coords = nullptr;
-    size_t lds2 = (size_t)Npad * 8;
-    if (lds2 > 64 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(1024), lds2, stream, cand, ncand, Npad, q, boxes_out, scores_out, labels_out, count_out);
+    const DecodeProblem d = {hm, center, center_z, dim, rot, vel, nullptr, nullptr, 0, cfg, boxes_out, scores_out, labels_out, count_out,
+                             workspace, workspace_bytes};
+    const int rc = check_decode(d, "aq3d_center_decode");
+    if (rc != AQ3D_OK) return rc;
+    launch_decode(&d, 1, (hipStream_t)stream_);
     AQ3D_CHECK_LAUNCH("aq3d_center_decode");
     return AQ3D_OK;
 }
@@ -435,45 +507,41 @@ extern "C" int aq3d_voxel_decode(const float *hm, const float *center, const flo
                                  const float *rot, const float *vel, const int32_t *coords, const int32_t *count, int32_t cap,
                                  const aq3d_decode_cfg *cfg, float *boxes_out, float *scores_out, int32_t *labels_out,
                                  int32_t *count_out, void *workspace, size_t workspace_bytes, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    AQ3D_REQUIRE(hm && center && center_z && dim && rot && coords && count && cfg && boxes_out && scores_out && labels_out &&
-                     count_out && workspace, "aq3d_voxel_decode: null argument");
-    AQ3D_REQUIRE(!cfg->has_vel || vel, "aq3d_voxel_decode: has_vel without vel rows");
-    AQ3D_REQUIRE(cfg->num_classes >= 1 && cfg->num_classes <= 16 && cfg->K >= 1 && cfg->K <= 512 && cap >= 1,
-                 "aq3d_voxel_decode: num_classes=%d K=%d cap=%d", cfg->num_classes, cfg->K, cap);
-    if (workspace_bytes < aq3d_center_decode_workspace_bytes(cfg)) {
-        aq3d_set_error("aq3d_voxel_decode: workspace too small");
-        return AQ3D_ERR_WORKSPACE;
-    }
-    const int K = cfg->K, Kpad = next_pow2(K);
-    u64 *cand = (u64 *)workspace;
-    size_t lds1 = (size_t)Kpad * 8 + 256 * 4 + 16 * 4;
-    const size_t key_bytes = (size_t)cap * 4 > 131072 ? (size_t)cap * 4 : 131072;
-    const int cache_keys = (lds1 + key_bytes <= 150 * 1024) ? 1 : 0;
-    if (cache_keys) lds1 += key_bytes;
-    if (lds1 > 64 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(topk_per_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    hipLaunchKernelGGL(topk_per_class_kernel, dim3(cfg->num_classes), dim3(1024), lds1, stream, hm, cfg->hm_ld, cap, count, K, Kpad,
-                       cache_keys, cfg->score_thresh, cand);
-    const int ncand = cfg->num_classes * K, Npad = next_pow2(ncand);
-    DecodeParams q;
-    q.c = *cfg; q.center = center; q.center_z = center_z; q.dim = dim; q.rot = rot; q.vel = vel; q.coords = coords;
-    size_t lds2 = (size_t)Npad * 8;
-    if (lds2 > 64 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-    hipLaunchKernelGGL(decode_kernel, dim3(1), dim3(1024), lds2, stream, cand, ncand, Npad, q, boxes_out, scores_out, labels_out, count_out);
+    AQ3D_REQUIRE(coords, "aq3d_voxel_decode: null coords");
+    const DecodeProblem d = {hm, center, center_z, dim, rot, vel, coords, count, cap, cfg, boxes_out, scores_out, labels_out, count_out,
+                             workspace, workspace_bytes};
+    const int rc = check_decode(d, "aq3d_voxel_decode");
+    if (rc != AQ3D_OK) return rc;
+    launch_decode(&d, 1, (hipStream_t)stream_);
     AQ3D_CHECK_LAUNCH("aq3d_voxel_decode");
     return AQ3D_OK;
 }
 
 // ------------------------------------------------------------------ rotated NMS (geometry: nms_geom.h)
 // one wave per (row box, column block): lane j tests box (cb*64 + j) against the row box, ballot -> one mask word
-__global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ boxes, int box_ld, const int *count, int cap,
-                                                      float thresh, int col_blocks, u64 *__restrict__ mask) {
-    int n = *count;
+struct NmsArgs {
+    const float *boxes;
+    int box_ld;
+    const int *count;
+    int cap;
+    float thresh;
+    int col_blocks, post_max, use_lds;
+    u64 *mask;
+    int *keep, *keep_count;
+};
+struct NmsBatch {
+    NmsArgs p[AQ3D_MAX_HEADS];
+};
+__global__ __launch_bounds__(64) void nms_mask_kernel(NmsBatch nb) {
+    const NmsArgs &q = nb.p[blockIdx.z];
+    const float *__restrict__ boxes = q.boxes;
+    const int box_ld = q.box_ld, cap = q.cap, col_blocks = q.col_blocks;
+    const float thresh = q.thresh;
+    u64 *__restrict__ mask = q.mask;
+    int n = *q.count;
     if (n > cap) n = cap;
     const int row = blockIdx.x, cb = blockIdx.y;
-    if (row >= n) return;
+    if (row >= n || cb >= col_blocks) return;
     __shared__ P2 pts_s[NMS_MAX_PTS * 64];
     const int rb = row >> 6;
     u64 word = 0ull;
@@ -494,8 +562,12 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const float *__restrict__ 
 
 // greedy sweep, 64 boxes per step; the bitmask is staged in LDS by the whole workgroup when it fits, then wave 0 sweeps:
 // lane w owns removal word w (cap <= 4096 → <= 64 words).
-__global__ __launch_bounds__(256) void nms_sweep_kernel(const u64 *__restrict__ mask, const int *count, int cap, int col_blocks,
-                                                       int post_max, int use_lds, int *__restrict__ keep, int *__restrict__ keep_count) {
+__global__ __launch_bounds__(256) void nms_sweep_kernel(NmsBatch nb_) {
+    const NmsArgs &q = nb_.p[blockIdx.x];
+    const u64 *__restrict__ mask = q.mask;
+    const int *count = q.count;
+    const int cap = q.cap, col_blocks = q.col_blocks, post_max = q.post_max, use_lds = q.use_lds;
+    int *__restrict__ keep = q.keep, *__restrict__ keep_count = q.keep_count;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *mask_s = reinterpret_cast<u64 *>(smem_raw);
     int n = *count;
@@ -552,54 +624,135 @@ extern "C" size_t aq3d_nms_workspace_bytes(int32_t cap) {
     return (size_t)cap * aq3d_div_up(cap, 64) * sizeof(u64) + 256;
 }
 
+struct NmsProblem {
+    const float *boxes;
+    int32_t box_ld;
+    const int32_t *count;
+    int32_t cap;
+    float thresh;
+    int32_t post_max;
+    int32_t *keep_out, *keep_count;
+    void *workspace;
+    size_t workspace_bytes;
+};
+
+static int check_nms(const NmsProblem &q, const char *who) {
+    AQ3D_REQUIRE(q.boxes && q.count && q.keep_out && q.keep_count && q.workspace, "%s: null argument", who);
+    AQ3D_REQUIRE(q.cap >= 1 && q.cap <= 4096 && q.box_ld >= 7 && q.post_max >= 1, "%s: cap=%d box_ld=%d post_max=%d", who, q.cap, q.box_ld,
+                 q.post_max);
+    if (q.workspace_bytes < aq3d_nms_workspace_bytes(q.cap)) {
+        aq3d_set_error("%s: workspace too small", who);
+        return AQ3D_ERR_WORKSPACE;
+    }
+    return AQ3D_OK;
+}
+
+// ballot mask + greedy sweep of n <= AQ3D_MAX_HEADS checked problems: two launches
+static void launch_nms(const NmsProblem *q, int n, hipStream_t stream) {
+    NmsBatch nb;
+    int max_cap = 1, max_cb = 1;
+    size_t lds = 0;
+    for (int i = 0; i < n; ++i) {
+        NmsArgs &a = nb.p[i];
+        a.boxes = q[i].boxes; a.box_ld = q[i].box_ld; a.count = q[i].count; a.cap = q[i].cap; a.thresh = q[i].thresh;
+        a.col_blocks = aq3d_div_up(q[i].cap, 64); a.post_max = q[i].post_max; a.mask = (u64 *)q[i].workspace;
+        a.keep = q[i].keep_out; a.keep_count = q[i].keep_count;
+        const size_t mask_bytes = (size_t)q[i].cap * a.col_blocks * sizeof(u64);
+        a.use_lds = mask_bytes <= 128 * 1024;
+        if (a.use_lds && mask_bytes > lds) lds = mask_bytes;
+        max_cap = q[i].cap > max_cap ? q[i].cap : max_cap;
+        max_cb = a.col_blocks > max_cb ? a.col_blocks : max_cb;
+    }
+    for (int i = n; i < AQ3D_MAX_HEADS; ++i) nb.p[i] = nb.p[0];
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(max_cap, max_cb, n), dim3(64), 0, stream, nb);
+    if (lds > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(n), dim3(256), lds, stream, nb);
+}
+
 extern "C" int aq3d_nms_rotated(const float *boxes, int32_t box_ld, const int32_t *count, int32_t cap, float thresh,
                                 int32_t post_max, int32_t *keep_out, int32_t *keep_count, void *workspace,
                                 size_t workspace_bytes, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    AQ3D_REQUIRE(boxes && count && keep_out && keep_count && workspace, "aq3d_nms_rotated: null argument");
-    AQ3D_REQUIRE(cap >= 1 && cap <= 4096 && box_ld >= 7 && post_max >= 1, "aq3d_nms_rotated: cap=%d box_ld=%d post_max=%d", cap, box_ld, post_max);
-    if (workspace_bytes < aq3d_nms_workspace_bytes(cap)) {
-        aq3d_set_error("aq3d_nms_rotated: workspace too small");
-        return AQ3D_ERR_WORKSPACE;
-    }
-    const int col_blocks = aq3d_div_up(cap, 64);
-    u64 *mask = (u64 *)workspace;
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(cap, col_blocks), dim3(64), 0, stream, boxes, box_ld, count, cap, thresh, col_blocks, mask);
-    const size_t mask_bytes = (size_t)cap * col_blocks * sizeof(u64);
-    const int use_lds = mask_bytes <= 128 * 1024;
-    if (use_lds && mask_bytes > 64 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(nms_sweep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mask_bytes);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(1), dim3(256), use_lds ? mask_bytes : 0, stream, mask, count, cap, col_blocks, post_max,
-                       use_lds, keep_out, keep_count);
+    const NmsProblem q = {boxes, box_ld, count, cap, thresh, post_max, keep_out, keep_count, workspace, workspace_bytes};
+    const int rc = check_nms(q, "aq3d_nms_rotated");
+    if (rc != AQ3D_OK) return rc;
+    launch_nms(&q, 1, (hipStream_t)stream_);
     AQ3D_CHECK_LAUNCH("aq3d_nms_rotated");
     return AQ3D_OK;
 }
 
-__global__ __launch_bounds__(256) void gather_dets_kernel(const float *__restrict__ boxes, int box_ld,
-                                                          const float *__restrict__ scores, const int *__restrict__ labels,
-                                                          const int *__restrict__ class_map, const int *__restrict__ keep,
-                                                          const int *keep_count, int cap, float *__restrict__ boxes_out,
-                                                          float *__restrict__ scores_out, long long *__restrict__ labels_out) {
-    int n = *keep_count;
-    if (n > cap) n = cap;
+struct GatherArgs {
+    const float *boxes;
+    int box_ld;
+    const float *scores;
+    const int *labels, *class_map, *keep, *keep_count;
+    int cap;
+    float *boxes_out, *scores_out;
+    long long *labels_out;
+};
+struct GatherBatch {
+    GatherArgs p[AQ3D_MAX_HEADS];
+};
+__global__ __launch_bounds__(256) void gather_dets_kernel(GatherBatch gb) {
+    const GatherArgs &a = gb.p[blockIdx.y];
+    int n = *a.keep_count;
+    if (n > a.cap) n = a.cap;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const int src = keep[i];
-        for (int j = 0; j < box_ld; ++j) boxes_out[(size_t)i * box_ld + j] = boxes[(size_t)src * box_ld + j];
-        scores_out[i] = scores[src];
-        const int lab = labels[src];
-        labels_out[i] = (long long)(class_map ? class_map[lab] : lab) + 1;  // center_head.py:363
+        const int src = a.keep[i];
+        for (int j = 0; j < a.box_ld; ++j) a.boxes_out[(size_t)i * a.box_ld + j] = a.boxes[(size_t)src * a.box_ld + j];
+        a.scores_out[i] = a.scores[src];
+        const int lab = a.labels[src];
+        a.labels_out[i] = (long long)(a.class_map ? a.class_map[lab] : lab) + 1;  // center_head.py:363
     }
+}
+
+static void launch_gather(const GatherArgs *g, int n, hipStream_t stream) {
+    GatherBatch gb;
+    int max_cap = 1;
+    for (int i = 0; i < n; ++i) { gb.p[i] = g[i]; max_cap = g[i].cap > max_cap ? g[i].cap : max_cap; }
+    for (int i = n; i < AQ3D_MAX_HEADS; ++i) gb.p[i] = gb.p[0];
+    hipLaunchKernelGGL(gather_dets_kernel, dim3(aq3d_grid(max_cap, 256), n), dim3(256), 0, stream, gb);
 }
 
 extern "C" int aq3d_gather_dets(const float *boxes, int32_t box_ld, const float *scores, const int32_t *labels,
                                 const int32_t *class_map, const int32_t *keep, const int32_t *keep_count, int32_t cap,
                                 float *boxes_out, float *scores_out, int64_t *labels_out, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     AQ3D_REQUIRE(boxes && scores && labels && keep && keep_count && boxes_out && scores_out && labels_out,
                  "aq3d_gather_dets: null argument");
-    hipLaunchKernelGGL(gather_dets_kernel, dim3(aq3d_grid(cap, 256)), dim3(256), 0, stream, boxes, box_ld, scores, labels,
-                       class_map, keep, keep_count, cap, boxes_out, scores_out, (long long *)labels_out);
+    const GatherArgs g = {boxes, box_ld, scores, labels, class_map, keep, keep_count, cap, boxes_out, scores_out, (long long *)labels_out};
+    launch_gather(&g, 1, (hipStream_t)stream_);
     AQ3D_CHECK_LAUNCH("aq3d_gather_dets");
+    return AQ3D_OK;
+}
+
+// The whole post-processing chain of up to AQ3D_MAX_HEADS heads in FIVE launches (top-K, decode, mask, sweep, gather):
+// center_head.py:297-365 / voxelnext_head.py:418-560 run it head after head.
+extern "C" int aq3d_decode_nms_batch(const aq3d_head_problem *heads, int32_t n, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AQ3D_REQUIRE(heads && n >= 1 && n <= AQ3D_MAX_HEADS, "aq3d_decode_nms_batch: n=%d not in 1..%d", n, AQ3D_MAX_HEADS);
+    DecodeProblem d[AQ3D_MAX_HEADS];
+    NmsProblem q[AQ3D_MAX_HEADS];
+    GatherArgs g[AQ3D_MAX_HEADS];
+    for (int i = 0; i < n; ++i) {
+        const aq3d_head_problem &h = heads[i];
+        AQ3D_REQUIRE(h.cfg, "aq3d_decode_nms_batch: head %d: null cfg", i);
+        const int nbox = h.cfg->has_vel ? 9 : 7;
+        d[i] = {h.hm, h.center, h.center_z, h.dim, h.rot, h.vel, h.coords, h.count, h.cap, h.cfg, h.cand_boxes, h.cand_scores, h.cand_labels,
+                h.cand_count, h.decode_workspace, h.decode_workspace_bytes};
+        int rc = check_decode(d[i], "aq3d_decode_nms_batch(decode)");
+        if (rc != AQ3D_OK) return rc;
+        AQ3D_REQUIRE(h.nms_cap >= 1 && h.nms_cap <= h.cfg->K, "aq3d_decode_nms_batch: head %d: nms_cap=%d K=%d", i, h.nms_cap, h.cfg->K);
+        q[i] = {h.cand_boxes, nbox, h.cand_count, h.nms_cap, h.nms_thresh, h.post_max, h.keep, h.keep_count, h.nms_workspace, h.nms_workspace_bytes};
+        rc = check_nms(q[i], "aq3d_decode_nms_batch(nms)");
+        if (rc != AQ3D_OK) return rc;
+        AQ3D_REQUIRE(h.boxes_out && h.scores_out && h.labels_out, "aq3d_decode_nms_batch: head %d: null output", i);
+        g[i] = {h.cand_boxes, nbox, h.cand_scores, h.cand_labels, h.class_map, h.keep, h.keep_count, h.nms_cap, h.boxes_out, h.scores_out,
+                (long long *)h.labels_out};
+    }
+    launch_decode(d, n, stream);
+    launch_nms(q, n, stream);
+    launch_gather(g, n, stream);
+    AQ3D_CHECK_LAUNCH("aq3d_decode_nms_batch");
     return AQ3D_OK;
 }
 

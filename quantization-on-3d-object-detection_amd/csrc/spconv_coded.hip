@@ -180,6 +180,8 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
     _Float16 *Bh = reinterpret_cast<_Float16 *>(smem_raw);          // [COUT][LD] hi, K index = offset * CIN + channel
     _Float16 *Bl = Bh + COUT * LD;                                   // [COUT][LD] lo (PL == 2 only)
     float *red = reinterpret_cast<float *>(Bh + PL * COUT * LD);     // [NW][COUT]
+    constexpr int NPW = 16 * KVOL;                                   // gather-table entries of a wave's 16 rows: contiguous in memory
+    int *nbr_s = reinterpret_cast<int *>(red + NW * COUT) + (threadIdx.x >> 6) * NPW;     // [NW][16 * KVOL], this wave's slice
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
@@ -199,27 +201,28 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int trow = tile * TMW + wave * 16 + l15;
-        int nb[KVOL];
+        // rulebook tile through LDS: the wave's 16 x KVOL gather-table entries are one contiguous block, loaded coalesced (7 dwords
+        // per lane) instead of KVOL strided 4-byte loads per lane, of which a lane uses every other one
+        const int rbase = tile * TMW + wave * 16;
+        __syncthreads();                                 // the previous tile's reads of nbr_s are done
 #pragma unroll
-        for (int k = 0; k < KVOL; ++k) {
-            const unsigned off = trow < n ? (unsigned)((trow * KVOL + k) * 4) : CD_OOB;
-            nb[k] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc_n, off, 0, 0);
+        for (int i = 0; i < (NPW + 63) / 64; ++i) {
+            const int e = lane + 64 * i;
+            if (NPW % 64 == 0 || e < NPW) {
+                const bool live = rbase + e / KVOL < n;
+                const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc_n, live ? (unsigned)((rbase * KVOL + e) * 4) : CD_OOB, 0, 0);
+                nbr_s[e] = live ? v : -1;
+            }
         }
-        if (trow >= n) {
-#pragma unroll
-            for (int k = 0; k < KVOL; ++k) nb[k] = -1;
-        }
+        __syncthreads();
         f32x4 acc[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int bofs = l15 * LD + 8 * g;
 #pragma unroll
         for (int q = 0; q < NCH; ++q) {
-            const int j0 = 2 * q, j1 = 2 * q + 1;
-            const int i0 = nb[j0 < KVOL ? j0 : KVOL - 1];
-            const int i1 = j1 < KVOL ? nb[j1 < KVOL ? j1 : KVOL - 1] : -1;
-            const int idx = (g >> 1) ? i1 : i0;
+            const int j = 2 * q + (g >> 1);              // kernel offset of this lane's half of the K chunk
+            const int idx = j < KVOL ? nbr_s[l15 * KVOL + (j < KVOL ? j : KVOL - 1)] : -1;
             const unsigned off = idx >= 0 ? (unsigned)(idx * CIN + (g & 1) * 8) : CD_OOB;
             const i32x2v cv = __builtin_amdgcn_raw_buffer_load_b64(rsrc_f, off, 0, 0);   // no neighbour: out of range, no traffic
             // none of the wave's 16 rows has a neighbour at these two offsets: skip the conversion, the LDS reads and the
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
 template <int COUT, int KVOL, int NW, int PL>
 static int launch_cd(const SpCodedArgs &a, hipStream_t stream) {
     constexpr int NCH = (KVOL * 16 + 31) / 32;
-    constexpr size_t lds = (size_t)PL * COUT * (NCH * 32 + 8) * 2 + NW * COUT * 4;
+    constexpr size_t lds = (size_t)PL * COUT * (NCH * 32 + 8) * 2 + NW * COUT * 4 + (size_t)NW * 16 * KVOL * 4;
     const int tiles = aq3d_div_up(a.cap_out, 16 * NW);
     const int grid = tiles < 2048 ? (tiles < 1 ? 1 : tiles) : 2048;
     auto kern = spconv_cd_kernel<COUT, KVOL, NW, PL>;

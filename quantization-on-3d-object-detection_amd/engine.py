@@ -137,6 +137,7 @@ class Engine:
         self.tensors = {}
         self._voxel_ws = None
         self.sparse_fp16_weights = bool(getattr(det, "sparse_fp16_weights", False))
+        self._head_args = {}
         self._force_rows = False     # teacher-forced tests: run the rows-only quantiser even where a producer epilogue does it
         if isinstance(det.backbone_3d, VoxelResBackBone8xVoxelNeXt):
             self.fully_sparse = True
@@ -997,30 +998,33 @@ class Engine:
         if wq_._if_calib:
             wq_.collect(amax_w)
 
-    def _for_each_head(self, body):
-        """The decode -> NMS -> gather chains of the heads, one after the other on the frame's stream. (Round 2 tried forked side
-        streams, which a captured hipGraph keeps as parallel branches: VoxelNeXt's 6 chains then overlap — p10 latency 4.15 -> 3.63 ms
-        — but throughput with two plans in flight fell from 297 to 176 frames/s: the graph's internal branch streams compete with
-        the other plan for the hardware queues. Batching the heads inside the kernels is the way, not done yet.)"""
-        for hi, h in enumerate(self.heads):
-            body(hi, h)
+    def _head_batches(self, b, make):
+        """ctypes problem arrays of aq3d_decode_nms_batch for result slot self.slot and sample b: <= 8 heads per launch, built once."""
+        key = (self.slot, b)
+        if key not in self._head_args:
+            recs = [make(hi, h) for hi, h in enumerate(self.heads)]
+            self._head_args[key] = [(ops.head_problems(recs[i:i + 8]), recs[i:i + 8]) for i in range(0, len(recs), 8)]
+        return self._head_args[key]
+
+    def _head_common(self, hi, h, b):
+        cap_nms = min(h["K"], h["pre"])
+        return dict(cfg=h["cfg"], cand=(h["cand_boxes"][b], h["cand_scores"][b], h["cand_labels"][b], h["cand_count"][b]),
+                    dec_ws=h["dec_ws"], thresh=h["thresh"], nms_cap=cap_nms, post_max=h["post"], keep=h["keep"][b],
+                    keep_count=self.det_counts[self.slot, b, hi:hi + 1], nms_ws=h["nms_ws"], class_map=h["class_map"],
+                    out=(h["out_boxes"][self.slot, b], h["out_scores"][self.slot, b], h["out_labels"][self.slot, b]))
 
     def _decode_nms(self, B):
-        def body(hi, h):
-            s = h["slots"]
-            for b in range(B):
+        """center_head.py:297-365 for every head: top-K, decode, rotated NMS, gather — five launches for up to 8 heads."""
+        for b in range(B):
+            def make(hi, h):
+                s = h["slots"]
                 buf = h["buf"][b].view(-1, self.HEAD_LD)
-                ops.center_decode(buf[:, s["hm"]:], buf[:, s["center"]:], buf[:, s["center_z"]:], buf[:, s["dim"]:],
-                                  buf[:, s["rot"]:], buf[:, s["vel"]:] if h["has_vel"] else None, h["cfg"],
-                                  workspace=h["dec_ws"],
-                                  out=(h["cand_boxes"][b], h["cand_scores"][b], h["cand_labels"][b], h["cand_count"][b]))
-                cap_nms = min(h["K"], h["pre"])
-                ops.nms_rotated(h["cand_boxes"][b][:cap_nms], h["cand_count"][b], h["thresh"], h["post"],
-                                workspace=h["nms_ws"], out=(h["keep"][b][:cap_nms], self.det_counts[self.slot, b, hi:hi + 1]))
-                ops.gather_dets(h["cand_boxes"][b][:cap_nms], h["cand_scores"][b][:cap_nms], h["cand_labels"][b][:cap_nms],
-                                h["class_map"], h["keep"][b][:cap_nms], self.det_counts[self.slot, b, hi:hi + 1],
-                                out=(h["out_boxes"][self.slot, b][:cap_nms], h["out_scores"][self.slot, b][:cap_nms], h["out_labels"][self.slot, b][:cap_nms]))
-        self._for_each_head(body)
+                r = self._head_common(hi, h, b)
+                r.update(hm=buf[:, s["hm"]:], center=buf[:, s["center"]:], center_z=buf[:, s["center_z"]:], dim=buf[:, s["dim"]:],
+                         rot=buf[:, s["rot"]:], vel=buf[:, s["vel"]:] if h["has_vel"] else None)
+                return r
+            for args, _ in self._head_batches(b, make):
+                ops.decode_nms_batch(args)
 
     def run_head_from(self, bev_nhwc):
         """Run only shared conv → head branches → decode → NMS on given BEV features [B, H, W, C] (parity tests feed
@@ -1248,19 +1252,15 @@ class Engine:
     def _voxel_decode_nms(self):
         b = 0
 
-        def body(hi, h):
+        def make(hi, h):
             lv = self.levels[h["level"]]
             o = h["outs"]
-            ops.voxel_decode(o["hm"]["buf"], o["center"]["buf"], o["center_z"]["buf"], o["dim"]["buf"], o["rot"]["buf"],
-                             o["vel"]["buf"] if h["has_vel"] else None, lv["coords"], lv["count"], h["cfg"], workspace=h["dec_ws"],
-                             out=(h["cand_boxes"][b], h["cand_scores"][b], h["cand_labels"][b], h["cand_count"][b]))
-            cap_nms = min(h["K"], h["pre"])
-            ops.nms_rotated(h["cand_boxes"][b][:cap_nms], h["cand_count"][b], h["thresh"], h["post"],
-                            workspace=h["nms_ws"], out=(h["keep"][b][:cap_nms], self.det_counts[self.slot, b, hi:hi + 1]))
-            ops.gather_dets(h["cand_boxes"][b][:cap_nms], h["cand_scores"][b][:cap_nms], h["cand_labels"][b][:cap_nms],
-                            h["class_map"], h["keep"][b][:cap_nms], self.det_counts[self.slot, b, hi:hi + 1],
-                            out=(h["out_boxes"][self.slot, b][:cap_nms], h["out_scores"][self.slot, b][:cap_nms], h["out_labels"][self.slot, b][:cap_nms]))
-        self._for_each_head(body)
+            r = self._head_common(hi, h, b)
+            r.update(hm=o["hm"]["buf"], center=o["center"]["buf"], center_z=o["center_z"]["buf"], dim=o["dim"]["buf"], rot=o["rot"]["buf"],
+                     vel=o["vel"]["buf"] if h["has_vel"] else None, coords=lv["coords"], count=lv["count"])
+            return r
+        for args, _ in self._head_batches(b, make):
+            ops.decode_nms_batch(args)
 
     def _index_down(self, li):
         lv_out = self.levels[li]

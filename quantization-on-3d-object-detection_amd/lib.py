@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class Aq3dError(RuntimeError):
@@ -33,6 +33,16 @@ class DecodeCfg(Structure):
                 ("feature_map_stride", c_float), ("voxel_size", c_float * 2), ("pc_range_min", c_float * 2),
                 ("post_center_range", c_float * 6), ("score_thresh", c_float), ("hm_ld", c_int32),
                 ("reg_ld", c_int32)]
+
+
+class HeadProblem(Structure):
+    _fields_ = [("hm", c_void_p), ("center", c_void_p), ("center_z", c_void_p), ("dim", c_void_p), ("rot", c_void_p), ("vel", c_void_p),
+                ("coords", c_void_p), ("count", c_void_p), ("cap", c_int32), ("cfg", POINTER(DecodeCfg)),
+                ("cand_boxes", c_void_p), ("cand_scores", c_void_p), ("cand_labels", c_void_p), ("cand_count", c_void_p),
+                ("decode_workspace", c_void_p), ("decode_workspace_bytes", c_size_t), ("nms_thresh", c_float), ("nms_cap", c_int32),
+                ("post_max", c_int32), ("keep", c_void_p), ("keep_count", c_void_p), ("nms_workspace", c_void_p),
+                ("nms_workspace_bytes", c_size_t), ("class_map", c_void_p), ("boxes_out", c_void_p), ("scores_out", c_void_p),
+                ("labels_out", c_void_p)]
 
 
 class Conv2dProblem(Structure):
@@ -95,6 +105,7 @@ SIGNATURES = {
     "aq3d_nms_workspace_bytes": (c_size_t, [c_int32]),
     "aq3d_nms_rotated": (c_int32, [P, c_int32, P, c_int32, c_float, c_int32, P, P, P, c_size_t, P]),
     "aq3d_gather_dets": (c_int32, [P, c_int32, P, P, P, P, P, c_int32, P, P, P, P]),
+    "aq3d_decode_nms_batch": (c_int32, [POINTER(HeadProblem), c_int32, P]),
     "aq3d_bev_merge_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "aq3d_bev_merge": (c_int32, [P, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, c_int32, P, P,
                                  c_int32, P, c_size_t, P]),

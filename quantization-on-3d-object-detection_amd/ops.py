@@ -508,6 +508,33 @@ def nms_rotated(boxes, count, thresh, post_max, workspace=None, out=None):
     return keep, kc
 
 
+def head_problems(recs):
+    """ctypes array of aq3d_head_problem from dicts(hm, center, center_z, dim, rot, vel, coords, count, cfg, cand=(boxes, scores,
+    labels, count), dec_ws, thresh, nms_cap, post_max, keep, keep_count, nms_ws, class_map, out=(boxes, scores, labels)). The caller
+    keeps every tensor (and cfg) alive."""
+    arr = (_lib.HeadProblem * len(recs))()
+    for q, r in zip(arr, recs):
+        q.hm, q.center, q.center_z, q.dim, q.rot = _addr(r["hm"]), _addr(r["center"]), _addr(r["center_z"]), _addr(r["dim"]), _addr(r["rot"])
+        q.vel, q.coords, q.count = _addr(r.get("vel")), _addr(r.get("coords")), _addr(r.get("count"))
+        q.cap = 0 if r.get("coords") is None else int(r["coords"].shape[0])
+        q.cfg = ctypes.pointer(r["cfg"])
+        cb, cs, cl, cc = r["cand"]
+        q.cand_boxes, q.cand_scores, q.cand_labels, q.cand_count = _addr(cb), _addr(cs), _addr(cl), _addr(cc)
+        q.decode_workspace, q.decode_workspace_bytes = _addr(r["dec_ws"]), int(r["dec_ws"].numel())
+        q.nms_thresh, q.nms_cap, q.post_max = float(r["thresh"]), int(r["nms_cap"]), int(r["post_max"])
+        q.keep, q.keep_count = _addr(r["keep"]), _addr(r["keep_count"])
+        q.nms_workspace, q.nms_workspace_bytes = _addr(r["nms_ws"]), int(r["nms_ws"].numel())
+        q.class_map = _addr(r.get("class_map"))
+        bo, so, lo = r["out"]
+        q.boxes_out, q.scores_out, q.labels_out = _addr(bo), _addr(so), _addr(lo)
+    return arr
+
+
+def decode_nms_batch(problems):
+    """top-K, decode, NMS mask, sweep and gather of up to 8 heads in five launches (aq3d_decode_nms_batch)."""
+    check(_lib.load().aq3d_decode_nms_batch(problems, len(problems), _stream()), "aq3d_decode_nms_batch")
+
+
 def gather_dets(boxes, scores, labels, class_map, keep, keep_count, out=None):
     """→ (boxes f32 [cap, ld], scores f32 [cap], labels i64 [cap]) rows [0, keep_count) valid; labels are 1-based."""
     L = _lib.load()

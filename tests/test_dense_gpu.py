@@ -235,6 +235,47 @@ def test_nms_empty_and_gather(dev):
     assert torch.equal(lo[:m], cmap[labels[k].long()].long() + 1)
 
 
+def test_decode_nms_batch_equals_head_by_head(dev):
+    """aq3d_decode_nms_batch (five launches for all heads) against aq3d_center_decode + aq3d_nms_rotated + aq3d_gather_dets head by
+    head: three heads with different class counts, map sizes, K and NMS capacities — every output bit for bit."""
+    from amdq3d import ops, lib
+    L = lib.load()
+    pc_range = [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
+    recs, singles = [], []
+    for hi, (H, W, ncls, K, pre, post, thr) in enumerate([(47, 47, 3, 100, 80, 50, 0.2), (188, 188, 1, 500, 500, 83, 0.7), (20, 12, 2, 64, 64, 500, 0.1)]):
+        hm, center, center_z, dim, rot = _head_maps(H, W, ncls, seed=H + K)
+        buf = np.zeros((H * W, 16), np.float32)
+        buf[:, 0:ncls] = hm.reshape(ncls, -1).T
+        buf[:, 4:6] = center.reshape(2, -1).T
+        buf[:, 6:7] = center_z.reshape(1, -1).T
+        buf[:, 8:11] = dim.reshape(3, -1).T * 0.3 + 1.0           # boxes large enough to overlap
+        buf[:, 12:14] = rot.reshape(2, -1).T
+        t = torch.from_numpy(buf).to(dev)
+        cfg = ops.make_decode_cfg(H, W, ncls, K, False, 8, [0.1, 0.1], pc_range, pc_range, 0.1, 16, 16)
+        cmap = torch.arange(ncls, dtype=torch.int32, device=dev).flip(0).contiguous()
+        cap = min(K, pre)
+        # head by head
+        bx, sc, lb, cnt = ops.center_decode(t, t[:, 4:], t[:, 6:], t[:, 8:], t[:, 12:], None, cfg)
+        keep, kc = ops.nms_rotated(bx[:cap], cnt, thr, post)
+        bo, so, lo = ops.gather_dets(bx[:cap], sc[:cap], lb[:cap], cmap, keep, kc)
+        singles.append((bx, sc, lb, cnt, keep, kc, bo, so, lo))
+        z = lambda *shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device=dev)
+        recs.append(dict(hm=t, center=t[:, 4:], center_z=t[:, 6:], dim=t[:, 8:], rot=t[:, 12:], vel=None, cfg=cfg,
+                         cand=(z(K, 7), z(K), z(K, dt=torch.int32), z(1, dt=torch.int32)),
+                         dec_ws=torch.empty((L.aq3d_center_decode_workspace_bytes(cfg),), dtype=torch.uint8, device=dev),
+                         thresh=thr, nms_cap=cap, post_max=post, keep=z(cap, dt=torch.int32), keep_count=z(1, dt=torch.int32),
+                         nms_ws=torch.empty((L.aq3d_nms_workspace_bytes(cap),), dtype=torch.uint8, device=dev), class_map=cmap,
+                         out=(z(cap, 7), z(cap), z(cap, dt=torch.int64))))
+    ops.decode_nms_batch(ops.head_problems(recs))
+    for r, (bx, sc, lb, cnt, keep, kc, bo, so, lo) in zip(recs, singles):
+        n, m = int(cnt.item()), int(kc.item())
+        assert n > 10 and 0 < m <= n
+        assert int(r["cand"][3].item()) == n and int(r["keep_count"].item()) == m
+        assert torch.equal(r["cand"][0][:n], bx[:n]) and torch.equal(r["cand"][1][:n], sc[:n]) and torch.equal(r["cand"][2][:n], lb[:n])
+        assert torch.equal(r["keep"][:m], keep[:m])
+        assert torch.equal(r["out"][0][:m], bo[:m]) and torch.equal(r["out"][1][:m], so[:m]) and torch.equal(r["out"][2][:m], lo[:m])
+
+
 def test_boxes_iou3d_and_recall_record(dev):
     """boxes_iou3d_gpu + generate_recall_record (detector3d_template.py:286-328) against the oracle."""
     from amdq3d import ops
