@@ -280,7 +280,6 @@ def main():
     ap.add_argument("--sparse-fp16-weights", action="store_true", help="quantised sparse convs multiply by ONE fp16 weight per product "
                     "(AQ3D_FLAG_W_FP16: the north star's int8 x fp16 precision, layers within 1e-3 of their output scale) instead of the "
                     "default fp16 hi|lo pair (layers within 2e-5)")
-    ap.add_argument("--stagger-ms", type=float, default=0.0, help="experiment: delay between the first `inflight` enqueues of a run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
@@ -334,8 +333,6 @@ def main():
         n_det = 0
         pending = collections.deque()
         for i in range(n_steps):
-            if args.stagger_ms > 0 and 0 < i < args.inflight:
-                time.sleep(args.stagger_ms * 1e-3)       # experiment: start the frames in flight out of phase with each other
             with torch.no_grad():
                 pending.append(model.forward_async(get_batch(i)))
             if len(pending) >= args.inflight:

@@ -607,6 +607,7 @@ extern "C" int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void
     do { \
         if (cin == 16 && cout == 16) return launch_cd<16, 27, 4, PL_>(a, stream); \
         if (cin == 16 && cout == 32) return launch_cd<32, 27, 8, PL_>(a, stream);    /* 58 KB of W' per workgroup: 8 waves share it */ \
+        /* (32 -> 32 with the whole W' resident like Cin = 16 — 110 KB, one workgroup per CU — measured 41 us against 30 us) */ \
         if (cin == 32 && cout == 32) return launch_cw<32, 32, 32, PL_>(a, stream); \
         if (cin == 32 && cout == 64) return launch_cw<32, 64, 64, PL_>(a, stream); \
         if (cin == 64 && cout == 64) return launch_cw<64, 64, 64, PL_>(a, stream); \
