@@ -404,6 +404,18 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
         if (f16w && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_I8 && a.cin == CIN_PAD) {
             bool same = true;
             for (int i = 1; i < n; ++i) same = same && grp.p[i].cin == CIN_PAD;
+            if (same && COUT == 128 && CIN_PAD == 128) {     // 64-row tiles (4 x 1 waves): the weights are re-streamed per tile (125 -> 100 us)
+                constexpr int TM2 = 64;
+                constexpr size_t lds3 = (size_t)(2 * TM2 + COUT) * (CIN_PAD + 8) * 2 + (size_t)TM2 * 27 * 4 + (size_t)4 * COUT * 4;
+                const int tiles2 = aq3d_div_up(a.cap_out, TM2);
+                const int grid2 = tiles2 < 2048 ? (tiles2 < 1 ? 1 : tiles2) : 2048;
+                auto kern = spconv_f16w_kernel<CIN_PAD, COUT, 4, 1>;
+                if (lds3 > 64 * 1024)
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                hipLaunchKernelGGL(kern, dim3(grid2, n), dim3(256), lds3, stream, grp);
+                AQ3D_CHECK_LAUNCH("aq3d_spconv");
+                return AQ3D_OK;
+            }
             if (same) {
                 constexpr size_t lds2 = (size_t)(2 * TM + COUT) * (CIN_PAD + 8) * 2 + (size_t)TM * 27 * 4 + (size_t)WR * COUT * 4;
                 auto kern = spconv_f16w_kernel<CIN_PAD, COUT, WR, WC>;
