@@ -297,15 +297,18 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
     constexpr int NCB = COUT / CT;                      // column blocks: a workgroup computes CT of the COUT output channels
     constexpr int TM = 4 * RT * 16;
     constexpr int NT = CT / 16;
-    constexpr int UC = CIN < 64 ? CIN : 64;
-    constexpr int NU = CIN / UC;
-    constexpr int KC = UC / 32;
-    constexpr bool SWZ = UC == 64;
-    constexpr int LDW = SWZ ? UC : UC + 8;              // halves per LDS weight row of one plane
+    // A unit is 64 K elements: a 64-channel slice of one kernel offset (Cin >= 64) or TWO kernel offsets x 32 channels (Cin = 32:
+    // K chunk 0 = first offset, chunk 1 = second; half as many staging rounds and barriers as one offset per unit).
+    constexpr bool PAIR = CIN == 32;
+    constexpr int UC = 64;
+    constexpr int NU = PAIR ? 1 : CIN / UC;
+    constexpr int KC = 2;
+    constexpr bool SWZ = true;
+    constexpr int LDW = UC;                              // halves per LDS weight row of one plane (XOR-swizzled 16-byte chunks)
     constexpr int PCH = CT * UC / 8;                  // 16-byte chunks of one plane of a unit
     constexpr int WCH = PL * PCH;                        // PL = 2: hi | lo planes of W'; 1: the hi plane only (AQ3D_FLAG_W_FP16)
     constexpr int NWL = (WCH + 255) / 256;
-    static_assert(CIN % 32 == 0 && CT % 16 == 0 && COUT % CT == 0, "channel granularity");
+    static_assert((CIN == 32 || CIN % 64 == 0) && CT % 16 == 0 && COUT % CT == 0, "channel granularity");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     _Float16 *Wb = reinterpret_cast<_Float16 *>(smem_raw);              // [2 buffers][PL planes][CT][LDW]
@@ -358,13 +361,14 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
 
     i32x4v A0[RT], A1[RT], wn[NWL];
     // chunk t of a unit: plane = t / PCH, row o, 16-byte chunk c8 of the UC-channel slice
-    auto loadW = [&](int k, int h) {
+    auto loadW = [&](int k, int h, int k2) {
 #pragma unroll
         for (int i = 0; i < NWL; ++i) {
             const int t = tid + 256 * i;
             const int pl = t / PCH, r = t % PCH;
             const int c8 = r % (UC / 8), o = r / (UC / 8);
-            const unsigned off = (unsigned)((((k * COUT + ob + o) * 2 + pl) * CIN + h * UC + c8 * 8) * 2);
+            const unsigned off = PAIR ? (unsigned)(((((c8 < 4 ? k : k2) * COUT + ob + o) * 2 + pl) * CIN + (c8 & 3) * 8) * 2)
+                                      : (unsigned)((((k * COUT + ob + o) * 2 + pl) * CIN + h * UC + c8 * 8) * 2);
             if (WCH % 256 == 0 || t < WCH)
                 wn[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0);   // k = kvol is past the end of the tensor: zeros
         }
@@ -387,37 +391,45 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
             src[rt] = k < kvol ? v : -1;
         }
     };
-    auto loadA1 = [&](i32x4v (&A)[RT], const int (&src)[RT], int h, int rt) {
-        if (UC == 64) {
+    auto loadA1 = [&](i32x4v (&A)[RT], const int (&src)[RT], const int (&src2)[RT], int h, int rt) {
+        if (!PAIR) {
             const unsigned off = src[rt] >= 0 ? (unsigned)src[rt] * (unsigned)CIN + (unsigned)(h * 64 + 16 * g) : CD_OOB;
             A[rt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, off, 0, 0);
-        } else {
+        } else {    // 8 channels of the lane's K group from each of the unit's two kernel offsets
             const unsigned off = src[rt] >= 0 ? (unsigned)src[rt] * (unsigned)CIN + (unsigned)(8 * g) : CD_OOB;
+            const unsigned off2 = src2[rt] >= 0 ? (unsigned)src2[rt] * (unsigned)CIN + (unsigned)(8 * g) : CD_OOB;
             const i32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrc_f, off, 0, 0);
-            A[rt] = (i32x4v){v.x, v.y, 0, 0};
+            const i32x2v v2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_f, off2, 0, 0);
+            A[rt] = (i32x4v){v.x, v.y, v2.x, v2.y};
         }
     };
-    auto loadA = [&](i32x4v (&A)[RT], int k, int h) {
-        int src[RT];
+    auto loadA = [&](i32x4v (&A)[RT], int k, int h, int k2) {
+        int src[RT], src2[RT];
         readSrc(src, k);
+        readSrc(src2, PAIR ? k2 : kvol);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) loadA1(A, src, h, rt);
+        for (int rt = 0; rt < RT; ++rt) loadA1(A, src, src2, h, rt);
     };
-    auto next_unit = [&](int &k, int &h) {
+    auto next_live = [&](int k) {
+        if (k >= kvol) return kvol;
+        const int rest = live & ~((2 << k) - 1);
+        return rest ? (__ffs(rest) - 1) : kvol;
+    };
+    auto next_unit = [&](int &k, int &h, int &k2) {
         if (k >= kvol) return;
         if (h + 1 < NU) { ++h; return; }
         h = 0;
-        const int rest = live & ~((2 << k) - 1);
-        k = rest ? (__ffs(rest) - 1) : kvol;
+        k = next_live(PAIR ? k2 : k);
+        if (PAIR) k2 = next_live(k);
     };
-    auto unit = [&](i32x4v (&Acur)[RT], i32x4v (&Anext)[RT], int b, int &k, int &h) {
-        next_unit(k, h);                                 // (k, h) now names the NEXT unit
-        loadW(k, h);
+    auto unit = [&](i32x4v (&Acur)[RT], i32x4v (&Anext)[RT], int b, int &k, int &h, int &k2) {
+        next_unit(k, h, k2);                             // (k, h, k2) now names the NEXT unit
+        loadW(k, h, k2);
         f16x8 F[RT][KC];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
             F[rt][0] = cd_cvt8(Acur[rt].x, Acur[rt].y);
-            if (KC == 2) F[rt][KC - 1] = cd_cvt8(Acur[rt].z, Acur[rt].w);
+            F[rt][1] = cd_cvt8(Acur[rt].z, Acur[rt].w);
         }
         // fragment j = (kc * NT + nt) * PL + plane: read FD ahead of the MFMAs that use it, each feeds RT MFMAs
         constexpr int NF = KC * NT * PL;
@@ -432,13 +444,14 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
         f16x8 fb[FD + 1];
 #pragma unroll
         for (int j = 0; j < FD && j < NF; ++j) fb[j] = frag(j);
-        int src[RT];
+        int src[RT], src2[RT];
         readSrc(src, k);
+        readSrc(src2, PAIR ? k2 : kvol);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NF; ++j) {
             if (j + FD < NF) fb[(j + FD) % (FD + 1)] = frag(j + FD);
-            if (j >= 1 && j <= LA) loadA1(Anext, src, h, j - 1);
+            if (j >= 1 && j <= LA) loadA1(Anext, src, src2, h, j - 1);
             __builtin_amdgcn_sched_barrier(0);
             const int nt = (j / PL) % NT, kc = (j / PL) / NT;
             const f16x8 f = fb[j % (FD + 1)];
@@ -447,20 +460,21 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int rt = LA; rt < RT; ++rt) loadA1(Anext, src, h, rt);
+        for (int rt = LA; rt < RT; ++rt) loadA1(Anext, src, src2, h, rt);
         storeW(b ^ 1);
         __syncthreads();
     };
 
     int k = live ? (__ffs(live) - 1) : kvol, h = 0;
-    const int nunits = __popc(live) * NU;
-    loadW(k, h);
-    loadA(A0, k, h);
+    int k2 = PAIR ? next_live(k) : kvol;
+    const int nunits = PAIR ? (__popc(live) + 1) / 2 : __popc(live) * NU;
+    loadW(k, h, k2);
+    loadA(A0, k, h, k2);
     storeW(0);
     __syncthreads();
     for (int u = 0; u < nunits; u += 2) {
-        unit(A0, A1, 0, k, h);
-        unit(A1, A0, 1, k, h);
+        unit(A0, A1, 0, k, h, k2);
+        unit(A1, A0, 1, k, h, k2);
     }
 
     // ---- epilogue (D layout: col = lane&15 -> out channel, row = 4g + reg -> tile row)
@@ -534,9 +548,8 @@ template <int CIN, int COUT, int CT, int PL>
 static int launch_cw(const SpCodedArgs &a, hipStream_t stream) {
     // 2 row tiles per wave (RT), fragments read 4 ahead (FD): measured round 2 against RT = 1 / 4 and FD = 8 (all slower)
     constexpr int RT = 2, FD = 4;
-    constexpr int UC = CIN < 64 ? CIN : 64;
     constexpr int TM = 64 * RT;
-    constexpr size_t lds = (size_t)2 * PL * CT * (UC == 64 ? UC : UC + 8) * 2 + (size_t)TM * 27 * 4 + (size_t)4 * CT * 4 + 64;
+    constexpr size_t lds = (size_t)2 * PL * CT * 64 * 2 + (size_t)TM * 27 * 4 + (size_t)4 * CT * 4 + 64;
     const int grid = aq3d_div_up(aq3d_div_up(a.cap_out, TM), 8) * 8 * (COUT / CT);
     auto kern = spconv_cw_kernel<CIN, COUT, CT, RT, FD, PL>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
