@@ -546,7 +546,8 @@ static int launch_cd(const SpCodedArgs &a, hipStream_t stream) {
 
 template <int CIN, int COUT, int CT, int PL>
 static int launch_cw(const SpCodedArgs &a, hipStream_t stream) {
-    // 2 row tiles per wave (RT), fragments read 4 ahead (FD): measured round 2 against RT = 1 / 4 and FD = 8 (all slower)
+    // 2 row tiles per wave (RT), fragments read 4 ahead (FD): measured round 2 against RT = 1 / 4 and FD = 8 (all slower; RT = 1 also
+    // at Cin = 32: 29.4 against 27.9 us). W' loads two units ahead (second register set): no change (71.9 / 47.0 / 28.4 us) — removed.
     constexpr int RT = 2, FD = 4;
     constexpr int TM = 64 * RT;
     constexpr size_t lds = (size_t)2 * PL * CT * 64 * 2 + (size_t)TM * 27 * 4 + (size_t)4 * CT * 4 + 64;
