@@ -288,6 +288,19 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
     }
 }
 
+// In-kernel cycle stamps of spconv_cw_kernel for scratch/cw_stamps.py (a separate diagnostic build with -DAQ3D_STAMPS; the product
+// library compiles none of it).
+#ifdef AQ3D_STAMPS
+__device__ unsigned long long *g_cw_stamps;          // [gridDim.x][4 waves][8]
+extern "C" int aq3d_diag_set_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cw_stamps), &p, sizeof(p)); }
+#define CW_NOW() ((unsigned long long)clock64())
+#define CW_STAMP(var) const unsigned long long var = CW_NOW()
+#define CW_ACC(acc, from, to) acc += (to) - (from)
+#else
+#define CW_STAMP(var)
+#define CW_ACC(acc, from, to)
+#endif
+
 // Cin >= 32. Unit of work = (kernel offset k, 64-channel slice h) [32 channels when Cin = 32]: the two W' planes of the
 // slice go through LDS (double buffered, XOR-swizzled 128-byte rows as in the round-1 wide kernel), the A fragments of the
 // wave's two 16-row tiles are gathered straight into registers: ONE bounded buffer load per row and unit (16 bytes = the
@@ -326,32 +339,68 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
     const int cb = bj % NCB, ob = cb * CT;
     const int row0 = ((bj / NCB) * 8 + ((int)blockIdx.x & 7)) * TM;
     if (row0 >= n) return;
+    CW_STAMP(t_start);
+#ifdef AQ3D_STAMPS
+    unsigned long long s_cvt = 0, s_mfma = 0, s_store = 0, s_bar = 0;
+#endif
     const auto rsrc_f = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, (int)a.codes_bytes, 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.wp, 0, kvol * COUT * 2 * CIN * 2, 0x00020000);
 
-    if (tid == 0) mask_s[0] = 0;
+    // the per-channel epilogue operands are fetched now: loading them after the unit loop put one more global round trip at the
+    // end of every workgroup (stamps, scratch/cw_stamps.py: prologue + epilogue were 45 % of the 32-channel kernel, 34 % at 64)
+    const float amax_seen = (a.absmax_out && tid < CT) ? a.absmax_out[ob + tid] : 0.f;      // guard of the final atomic max
+    float e_mul[NT], e_bs[NT], e_ps[NT], e_pt[NT], e_nsc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int o = ob + nt * 16 + l15;
+        e_mul[nt] = a.out_mul[o];
+        e_bs[nt] = a.bias ? a.bias[o] : 0.f;
+        e_ps[nt] = a.post_scale ? a.post_scale[o] : 1.f;
+        e_pt[nt] = a.post_shift ? a.post_shift[o] : 0.f;
+        e_nsc[nt] = a.next_codes ? a.next_scale[o] : 0.f;
+    }
+    // gather-table tile -> LDS with 16-byte loads; the 27-bit "some row has this neighbour" mask is built from the loaded values
+    // (OR over the wave by shuffles, one LDS word per wave) instead of a second pass over the staged table behind a barrier
     {
         const int rows = n - row0 < TM ? n - row0 : TM;
-        const auto rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void *)(a.nbr + (size_t)row0 * kvol), 0, rows * kvol * 4, 0x00020000);
-        int v[(TM * 27 + 255) / 256];
+        const int lim = rows * kvol, total = TM * kvol;                       // total % 4 == 0 (TM = 128)
+        const int alloc = (a.cap_out - row0 < TM ? a.cap_out - row0 : TM) * kvol;    // dwords of the table that exist from row0 on
+        const int *src = a.nbr + (size_t)row0 * kvol;
+        constexpr int NQ = (TM * 27 / 4 + 255) / 256;
+        i32x4v v[NQ];
 #pragma unroll
-        for (int i = 0; i < (TM * 27 + 255) / 256; ++i) v[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_n, (tid + 256 * i) * 4, 0, 0);
-        const int lim = rows * kvol;
-#pragma unroll
-        for (int i = 0; i < (TM * 27 + 255) / 256; ++i) {
-            const int t = tid + 256 * i;
-            if (t < TM * kvol) nbr_s[t] = t < lim ? v[i] : -1;
+        for (int i = 0; i < NQ; ++i) {
+            const int t4 = (tid + 256 * i) * 4;
+            v[i] = (i32x4v){-1, -1, -1, -1};
+            if (t4 + 3 < alloc) v[i] = *reinterpret_cast<const i32x4v *>(src + t4);
+            else if (t4 < alloc) {
+                v[i].x = src[t4];
+                if (t4 + 1 < alloc) v[i].y = src[t4 + 1];
+                if (t4 + 2 < alloc) v[i].z = src[t4 + 2];
+            }
         }
-    }
-    __syncthreads();
-    if (tid < TM) {
         int bits = 0;
-        for (int k = 0; k < kvol; ++k)
-            if (nbr_s[tid * kvol + k] >= 0) bits |= 1 << k;
-        if (bits) atomicOr(&mask_s[0], bits);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int t4 = (tid + 256 * i) * 4;
+            if (t4 < total) {
+                int kk = t4 % kvol;
+                int e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (t4 + j >= lim) e[j] = -1;
+                    if (e[j] >= 0) bits |= 1 << kk;
+                    kk = kk + 1 == kvol ? 0 : kk + 1;
+                }
+                *reinterpret_cast<i32x4v *>(nbr_s + t4) = (i32x4v){e[0], e[1], e[2], e[3]};
+            }
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) bits |= __shfl_xor(bits, d, 64);
+        if (lane == 0) mask_s[wave] = bits;
     }
     __syncthreads();
-    const int live = mask_s[0];
+    const int live = mask_s[0] | mask_s[1] | mask_s[2] | mask_s[3];
 
     f32x4 acc[RT][NT];
 #pragma unroll
@@ -423,6 +472,7 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
         if (PAIR) k2 = next_live(k);
     };
     auto unit = [&](i32x4v (&Acur)[RT], i32x4v (&Anext)[RT], int b, int &k, int &h, int &k2) {
+        CW_STAMP(ta);
         next_unit(k, h, k2);                             // (k, h, k2) now names the NEXT unit
         loadW(k, h, k2);
         f16x8 F[RT][KC];
@@ -431,6 +481,10 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
             F[rt][0] = cd_cvt8(Acur[rt].x, Acur[rt].y);
             F[rt][1] = cd_cvt8(Acur[rt].z, Acur[rt].w);
         }
+#ifdef AQ3D_STAMPS
+        asm volatile("" :: "v"(F[0][0]), "v"(F[RT - 1][1]));
+#endif
+        CW_STAMP(tb);
         // fragment j = (kc * NT + nt) * PL + plane: read FD ahead of the MFMAs that use it, each feeds RT MFMAs
         constexpr int NF = KC * NT * PL;
         constexpr int LA = NF - 1 < RT ? NF - 1 : RT;        // next unit's A loads issued inside the MFMA loop (the rest after it)
@@ -461,10 +515,15 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
         }
 #pragma unroll
         for (int rt = LA; rt < RT; ++rt) loadA1(Anext, src, src2, h, rt);
+        CW_STAMP(tc);
         storeW(b ^ 1);
+        CW_STAMP(td);
         __syncthreads();
+        CW_STAMP(te);
+        CW_ACC(s_cvt, ta, tb); CW_ACC(s_mfma, tb, tc); CW_ACC(s_store, tc, td); CW_ACC(s_bar, td, te);
     };
 
+    CW_STAMP(t_pro);
     int k = live ? (__ffs(live) - 1) : kvol, h = 0;
     int k2 = PAIR ? next_live(k) : kvol;
     const int nunits = PAIR ? (__popc(live) + 1) / 2 : __popc(live) * NU;
@@ -472,10 +531,12 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
     loadA(A0, k, h, k2);
     storeW(0);
     __syncthreads();
+    CW_STAMP(t_fill);
     for (int u = 0; u < nunits; u += 2) {
         unit(A0, A1, 0, k, h, k2);
         unit(A1, A0, 1, k, h, k2);
     }
+    CW_STAMP(t_loop);
 
     // ---- epilogue (D layout: col = lane&15 -> out channel, row = 4g + reg -> tile row)
     int mrow[RT][4];
@@ -490,11 +551,7 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int o = ob + nt * 16 + l15;
-        const float mul = a.out_mul[o];
-        const float bs = a.bias ? a.bias[o] : 0.f;
-        const float ps = a.post_scale ? a.post_scale[o] : 1.f;
-        const float pt = a.post_shift ? a.post_shift[o] : 0.f;
-        const float nsc = a.next_codes ? a.next_scale[o] : 0.f;
+        const float mul = e_mul[nt], bs = e_bs[nt], ps = e_ps[nt], pt = e_pt[nt], nsc = e_nsc[nt];
         const int npos = cd_code_pos(o, COUT);
         float mx = 0.f;
 #pragma unroll
@@ -523,11 +580,19 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
             for (int nt = 0; nt < NT; ++nt) red[wave * CT + nt * 16 + l15] = cmax[nt];
         }
         __syncthreads();
-        for (int o = tid; o < CT; o += 256) {
-            const float mx = fmaxf(fmaxf(red[o], red[CT + o]), fmaxf(red[2 * CT + o], red[3 * CT + o]));
-            if (mx > a.absmax_out[ob + o]) aq3d_atomic_max_pos(&a.absmax_out[ob + o], mx);
+        if (tid < CT) {     // CT <= 256; the guard value was read at kernel start (a stale, lower value only costs a redundant atomic)
+            const float mx = fmaxf(fmaxf(red[tid], red[CT + tid]), fmaxf(red[2 * CT + tid], red[3 * CT + tid]));
+            if (mx > amax_seen) aq3d_atomic_max_pos(&a.absmax_out[ob + tid], mx);
         }
     }
+#ifdef AQ3D_STAMPS
+    if (lane == 0 && g_cw_stamps) {
+        unsigned long long *o = g_cw_stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        const unsigned long long t_end = CW_NOW();
+        o[0] = t_pro - t_start; o[1] = t_fill - t_pro; o[2] = s_cvt; o[3] = s_mfma; o[4] = s_store; o[5] = s_bar;
+        o[6] = t_end - t_loop; o[7] = ((unsigned long long)nunits << 48) | (t_end - t_start);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ host side
