@@ -81,6 +81,17 @@ __device__ __forceinline__ int quant_pack4(f32x4 v, f32x4 s, f32x4 r, float sxv)
     return (int)(lo | hi);
 }
 
+// In-kernel cycle stamps of conv2d_i8_kernel for scratch/cw_stamps.py --dense (diagnostic build with -DAQ3D_STAMPS only).
+#ifdef AQ3D_STAMPS
+__device__ unsigned long long *g_i8_stamps;          // [workgroups][waves][8]
+extern "C" int aq3d_diag_set_i8_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_i8_stamps), &p, sizeof(p)); }
+#define I8_STAMP(var) const unsigned long long var = (unsigned long long)clock64()
+#define I8_ACC(acc, from, to) acc += (to) - (from)
+#else
+#define I8_STAMP(var)
+#define I8_ACC(acc, from, to)
+#endif
+
 // ------------------------------------------------------------------ int8 SmoothQuant conv
 // NWN = wave columns (2: 256 threads, 4: 512 threads). The K loop is a per-step dependency chain (global load -> quantise ->
 // LDS -> barrier -> MFMA); 8 waves split the staging work of a step in half and give every SIMD a second wave to interleave.
@@ -112,6 +123,10 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     const int bx = a.xcd_order ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int pix0 = bx * BN;
     if (pix0 >= L) return;
+    I8_STAMP(t_start);
+#ifdef AQ3D_STAMPS
+    unsigned long long s_load = 0, s_mma = 0, s_store = 0, s_bar = 0;
+#endif
     const int oc0 = blockIdx.y * BM;
     const int cchunks = a.Cin >> 6;
     if (a.pieces_out)
@@ -220,25 +235,39 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     // The whole K loop exists twice, with and without the clamp of calibrated (static) scales: a wave-uniform branch INSIDE the loop
     // made the register allocator rotate the accumulators through other AGPRs every step (40 v_accvgpr_* per step on top of ~110
     // useful VALU instructions, each waiting for the MFMA that produced its source).
+    I8_STAMP(t_pro);
+#ifdef AQ3D_STAMPS
+    unsigned long long t_fill_v = 0;
+#endif
     auto k_loop = [&](auto clamp_c) {
         load_step(stA, 0);
         store_step(clamp_c, stA, 0);
         __syncthreads();
+#ifdef AQ3D_STAMPS
+        t_fill_v = (unsigned long long)clock64();
+#endif
         // branch-free steady state (the last step is peeled): conditionals around the loads / stores inside the loop made the
         // compiler shuttle all accumulators between VGPRs and AGPRs every K step
         for (int k = 0; k + 1 < nk; ++k) {
             const int buf = k & 1;
+            I8_STAMP(ta);
             load_step(stA, k + 1);
             __builtin_amdgcn_sched_barrier(0);
+            I8_STAMP(tb);
             mma_step(buf);
             __builtin_amdgcn_sched_barrier(0);
+            I8_STAMP(tc);
             store_step(clamp_c, stA, buf ^ 1);
+            I8_STAMP(td);
             __syncthreads();
+            I8_STAMP(te);
+            I8_ACC(s_load, ta, tb); I8_ACC(s_mma, tb, tc); I8_ACC(s_store, tc, td); I8_ACC(s_bar, td, te);
         }
         mma_step((nk - 1) & 1);
     };
     if (clamp) k_loop(std::true_type{});
     else k_loop(std::false_type{});
+    I8_STAMP(t_loop);
 
     // epilogue: lane holds oc = base + 4g .. 4g+3 for pixel column l15
     float mint[4] = {0.f, 0.f, 0.f, 0.f};
@@ -323,6 +352,14 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
             }
         }
     }
+#ifdef AQ3D_STAMPS
+    if (lane == 0 && g_i8_stamps) {
+        unsigned long long *o = g_i8_stamps + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NTH / 64) + wave) * 8;
+        const unsigned long long t_end = (unsigned long long)clock64();
+        o[0] = t_pro - t_start; o[1] = t_fill_v - t_pro; o[2] = s_load; o[3] = s_mma; o[4] = s_store; o[5] = s_bar;
+        o[6] = t_end - t_loop; o[7] = ((unsigned long long)nk << 48) | (t_end - t_start);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ fp32 conv / transposed conv

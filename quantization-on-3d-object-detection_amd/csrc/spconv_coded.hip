@@ -191,6 +191,18 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
     const auto rsrc_f = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, (int)a.codes_bytes, 0x00020000);
     const auto rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, a.cap_out * KVOL * 4, 0x00020000);
 
+    // per-channel epilogue operands and the guard of the final atomic max: fetched before the weight staging, not at the tail
+    float e_mul[NT], e_b[NT], e_ps[NT], e_pt[NT], e_nsc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int o = nt * 16 + l15;
+        e_mul[nt] = a.out_mul[o];
+        e_b[nt] = a.bias ? a.bias[o] : 0.f;
+        e_ps[nt] = a.post_scale ? a.post_scale[o] : 1.f;
+        e_pt[nt] = a.post_shift ? a.post_shift[o] : 0.f;
+        e_nsc[nt] = a.next_codes ? a.next_scale[o] : 0.f;
+    }
+    float amax_seen = (a.absmax_out && tid < COUT) ? a.absmax_out[tid] : 0.f;
     for (int t = tid; t < PL * COUT * (LD / 8); t += NTH) {
         const int pl = t / (COUT * (LD / 8)), r = t % (COUT * (LD / 8));
         const int o = r / (LD / 8), kk = (r % (LD / 8)) * 8;
@@ -245,11 +257,7 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int o = nt * 16 + l15;
-            const float mul = a.out_mul[o];
-            const float b = a.bias ? a.bias[o] : 0.f;
-            const float ps = a.post_scale ? a.post_scale[o] : 1.f;
-            const float pt = a.post_shift ? a.post_shift[o] : 0.f;
-            const float nsc = a.next_codes ? a.next_scale[o] : 0.f;
+            const float mul = e_mul[nt], b = e_b[nt], ps = e_ps[nt], pt = e_pt[nt], nsc = e_nsc[nt];
             const int npos = cd_code_pos(o, COUT);
             float mx = 0.f;
 #pragma unroll
@@ -278,11 +286,14 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
                 for (int nt = 0; nt < NT; ++nt) red[wave * COUT + nt * 16 + l15] = cmax[nt];
             }
             __syncthreads();
-            for (int o = tid; o < COUT; o += NTH) {
-                float mx = red[o];
+            if (tid < COUT) {       // COUT <= 64 * NW; guard read at kernel start (stale and lower only costs a redundant atomic)
+                float mx = red[tid];
 #pragma unroll
-                for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w * COUT + o]);
-                if (mx > a.absmax_out[o]) aq3d_atomic_max_pos(&a.absmax_out[o], mx);
+                for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w * COUT + tid]);
+                if (mx > amax_seen) {
+                    aq3d_atomic_max_pos(&a.absmax_out[tid], mx);
+                    amax_seen = mx;
+                }
             }
         }
     }

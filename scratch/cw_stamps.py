@@ -39,11 +39,51 @@ def build_stamped():
     return out
 
 
+def dense(path, ops):
+    dev = torch.device("cuda:0")
+    raw = ctypes.CDLL(path)
+    g_ = torch.Generator().manual_seed(3)
+    for (H, W, Cin, Cout, s_) in [(188, 188, 128, 128, 1), (188, 188, 256, 128, 1), (94, 94, 256, 256, 1), (188, 188, 512, 64, 1)]:
+        x = (torch.relu(torch.randn(H, W, Cin, generator=g_)) * (torch.rand(Cin, generator=g_) * 3 + 0.1)).to(dev)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g_) / (9 * Cin) ** 0.5
+        geom = ops.conv_geom(H, W, Cin, Cout, 3, s_, 1, relu=True)
+        wk = ops.conv_weight_to_k(w).to(dev)
+        params = ops.sq_prep(ops.piece_absmax(x, H, W, Cin), wk, wk.abs().max(dim=0)[0].contiguous(), geom, 0.5)
+        ps, pt = (torch.rand(Cout, generator=g_) + 0.5).to(dev), (torch.randn(Cout, generator=g_) * 0.1).to(dev)
+        y = torch.empty((geom.Ho, geom.Wo, Cout), device=dev)
+        po = torch.zeros((16, Cout), device=dev)
+        stamps = torch.zeros((8192, 8), dtype=torch.int64, device=dev)
+        run = lambda: ops.conv2d_i8(x, params, geom, post_scale=ps, post_shift=pt, out=y, pieces_out=po, pieces_mode=1)
+        for _ in range(3):
+            run()
+        assert raw.aq3d_diag_set_i8_stamps(ctypes.c_void_p(stamps.data_ptr())) == 0
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        run()
+        t1.record()
+        torch.cuda.synchronize()
+        raw.aq3d_diag_set_i8_stamps(ctypes.c_void_p(0))
+        s = stamps.cpu().numpy()
+        s = s[s[:, 7] != 0]
+        steps = (s[:, 7] >> 48).astype(np.float64)
+        total = (s[:, 7] & ((1 << 48) - 1)).astype(np.float64)
+        names = ["prologue", "fill (first step)", "load issue", "LDS reads + MFMA", "wait + quantise + store", "barrier", "epilogue"]
+        print("conv2d_i8 %dx%d %d->%d: %d live waves, kernel %.1f us (with stamps); ticks per wave, mean (share of the wave's total):"
+              % (H, W, Cin, Cout, len(s), t0.elapsed_time(t1) * 1e3))
+        for i, nme in enumerate(names):
+            v = s[:, i].astype(np.float64)
+            print("  %-24s %9.0f  (%4.1f %%)%s" % (nme, v.mean(), 100 * v.sum() / total.sum(),
+                                                 "   per step %.0f" % (v.sum() / np.maximum(steps - 1, 1).sum()) if 2 <= i <= 5 else ""))
+        print("  %-24s %9.0f   K steps %.0f" % ("total", total.mean(), steps.mean()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--voxels", type=int, default=35000)
     ap.add_argument("--channels", type=int, nargs="+", default=[32, 64, 128])
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--dense", action="store_true", help="conv2d_i8_kernel on the benchmark's BEV layers instead of spconv_cw_kernel")
     args = ap.parse_args()
     path = build_stamped()
     if args.build_only:
@@ -51,6 +91,8 @@ def main():
         return
     L = lib.load(path)
     from amdq3d import ops
+    if args.dense:
+        return dense(path, ops)
     import subm_layer as SL
     dev = torch.device("cuda:0")
     shape = [41, 1504, 1504]
