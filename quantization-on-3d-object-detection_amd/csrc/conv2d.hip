@@ -109,6 +109,7 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     static_assert(BM >= 64, "BM >= 64");
     __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * LD];
     __shared__ unsigned int pm[16 * BM];     // piece maxima of this workgroup's outputs (bit patterns of |v|, v >= 0)
+    __shared__ __attribute__((aligned(16))) float ep[4][BM];   // epilogue operands of the block's channels: out_mul, bias, post_scale, post_shift
     auto Wbuf = [&](int b) -> char * { return smem + b * (BM + BN) * LD; };
     auto Xbuf = [&](int b) -> char * { return smem + b * (BM + BN) * LD + BM * LD; };
 
@@ -131,6 +132,14 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     const int cchunks = a.Cin >> 6;
     if (a.pieces_out)
         for (int i = tid; i < 16 * BM; i += NTH) pm[i] = 0u;      // ordered before its use by the K loop's barriers
+    for (int i = tid; i < BM; i += NTH) {                          // read back after the K loop (its barriers order the two)
+        const int oc = oc0 + i;
+        const bool in = oc < a.Cout;
+        ep[0][i] = in ? a.out_mul[oc] : 0.f;
+        ep[1][i] = (in && a.bias) ? a.bias[oc] : 0.f;
+        ep[2][i] = (in && a.post_scale) ? a.post_scale[oc] : 1.f;
+        ep[3][i] = (in && a.post_scale) ? a.post_shift[oc] : 0.f;
+    }
     const int ntaps = a.ks * a.ks;
     const int nk = ntaps * cchunks;
     const float sx = a.scal[0];
@@ -180,13 +189,17 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
         wrow_off[i] = min(oc0 + (item >> 2), a.Cout - 1) * K + (item & 3) * 16;
     }
 
-    auto load_step = [&](Stage &st, int kstep) {
+    // K steps are issued strictly in order 0, 1, 2, ...: (tap, kh, kw, channel chunk) advance as counters (two integer divisions by
+    // run-time values per step were a visible part of the 380 cycles a wave spent ISSUING a step's loads, scratch/cw_stamps.py)
+    int ls_tap = 0, ls_kh = 0, ls_kw = 0, ls_c0 = 0;
+    auto load_step = [&](Stage &st, int) {
         // K order: channel chunk outermost, the taps of one chunk back to back — the nine taps re-read the same fp32 pixels
         // (shifted by a pixel or a row), so their re-use distance is one step (16 KB per workgroup) instead of Cin/64 steps:
         // with tap-major order the 512-channel head conv fetched its input 8.6x from beyond L2. int32 sums: order-free.
-        const int chunk = kstep / ntaps, tap = kstep - chunk * ntaps, c0 = chunk << 6;
-        const int kh = tap / a.ks, kw = tap - kh * a.ks;
-        const int toff = (kh * a.W + kw) * a.in_ld + c0;      // wave-uniform
+        const int tap = ls_tap, c0 = ls_c0;
+        const int toff = (ls_kh * a.W + ls_kw) * a.in_ld + c0;      // wave-uniform
+        if (++ls_kw == a.ks) { ls_kw = 0; ++ls_kh; }
+        if (++ls_tap == ntaps) { ls_tap = 0; ls_kh = 0; ls_kw = 0; ls_c0 += 64; }
         const unsigned col = (unsigned)(tap * a.Cin + c0 + cq * 4) * 4u;
         st.sr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, col, 0, 0));
         st.rr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, col, 0, 0));
@@ -269,8 +282,10 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     else k_loop(std::false_type{});
     I8_STAMP(t_loop);
 
-    // epilogue: lane holds oc = base + 4g .. 4g+3 for pixel column l15
-    float mint[4] = {0.f, 0.f, 0.f, 0.f};
+    // epilogue: lane holds oc = base + 4g .. 4g+3 for pixel column l15. Order (stamps, scratch/cw_stamps.py --dense: the epilogue was
+    // 28 % of the 128 -> 128 layer): operands from LDS (staged at kernel start), values into registers, the output's piece maxima
+    // (interior: DPP row reduction over the 16 pixel lanes, no LDS shuffles), barrier + flush, and the 16-byte output stores LAST —
+    // nothing waits for them.
     int pcls[TJ];                           // piece class of this lane's TJ pixels; -1 = interior in merged mode
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
@@ -282,21 +297,17 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
                           ? -1 : piece_cls(ho, a.Ho) * 4 + piece_cls(wo, a.Wo);
         }
     }
+    f32x4 vout[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-        const int oc = oc0 + wm * (BM / 2) + i * 16 + 4 * g;
-        if (oc >= a.Cout) continue;
-        const f32x4 mul = *reinterpret_cast<const f32x4 *>(a.out_mul + oc);
-        f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f}, ps = (f32x4){1.f, 1.f, 1.f, 1.f}, pt = b;
-        if (a.bias) b = *reinterpret_cast<const f32x4 *>(a.bias + oc);
-        if (a.post_scale) {
-            ps = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
-            pt = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
-        }
+        const int ol = wm * (BM / 2) + i * 16 + 4 * g;       // channel inside the workgroup's block
+        const int oc = oc0 + ol;
+        const f32x4 mul = *reinterpret_cast<const f32x4 *>(&ep[0][ol]), b = *reinterpret_cast<const f32x4 *>(&ep[1][ol]);
+        const f32x4 ps = *reinterpret_cast<const f32x4 *>(&ep[2][ol]), pt = *reinterpret_cast<const f32x4 *>(&ep[3][ol]);
+        float mint[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int p = pix0 + wn * (BN / NWN) + j * 16 + l15;
-            if (p >= L) continue;
             f32x4 v;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -306,30 +317,29 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
                 if (a.relu) t = fmaxf(t, 0.f);
                 v[r] = t;
             }
-            *reinterpret_cast<f32x4 *>(a.y + (size_t)p * a.out_ld + a.out_coff + oc) = v;
-            if (a.pieces_out) {
+            vout[i][j] = v;
+            if (a.pieces_out && p < L && oc < a.Cout) {
                 if (pcls[j] < 0) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mint[r] = fmaxf(mint[r], fabsf(v[r]));      // interior: reduced in registers below
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicMax(&pm[pcls[j] * BM + (oc - oc0) + r], __float_as_uint(fabsf(v[r])));
+                    for (int r = 0; r < 4; ++r) atomicMax(&pm[pcls[j] * BM + ol + r], __float_as_uint(fabsf(v[r])));
                 }
             }
         }
         if (a.pieces_out && a.pieces_mode == 1) {
-            // interior pixels (98 % of the image): max over this wave's pixel columns with 4 xor-shuffles per value, then ONE
-            // LDS atomic per (wave, channel) instead of one per (pixel, channel) — same-address LDS atomics from the 16 pixel
-            // lanes were what made the fused epilogue slower than a separate pass
+            // interior pixels (98 % of the image): max over this wave's 16 pixel lanes = one DPP row (lanes 16g .. 16g+15), four
+            // row_shr steps leave it in the row's last lane, then ONE LDS atomic per (wave, channel). Values are >= 0: the zeros
+            // DPP feeds for lanes without a source are neutral.
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float m = mint[r];
-                m = fmaxf(m, __shfl_xor(m, 1, 64));
-                m = fmaxf(m, __shfl_xor(m, 2, 64));
-                m = fmaxf(m, __shfl_xor(m, 4, 64));
-                m = fmaxf(m, __shfl_xor(m, 8, 64));
-                if (l15 == 0 && m > 0.f) atomicMax(&pm[10 * BM + (oc - oc0) + r], __float_as_uint(m));
-                mint[r] = 0.f;
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x111, 0xf, 0xf, true)));
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x112, 0xf, 0xf, true)));
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x114, 0xf, 0xf, true)));
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x118, 0xf, 0xf, true)));
+                if (l15 == 15 && m > 0.f) atomicMax(&pm[10 * BM + ol + r], __float_as_uint(m));
             }
         }
     }
@@ -350,6 +360,16 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
                     atomicMax(reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc2 * a.pieces_ld + a.out_coff + oc, v);
                 } else if (v > *dst) atomicMax(dst, v);
             }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int oc = oc0 + wm * (BM / 2) + i * 16 + 4 * g;
+        if (oc >= a.Cout) continue;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int p = pix0 + wn * (BN / NWN) + j * 16 + l15;
+            if (p < L) *reinterpret_cast<f32x4 *>(a.y + (size_t)p * a.out_ld + a.out_coff + oc) = vout[i][j];
         }
     }
 #ifdef AQ3D_STAMPS
