@@ -102,7 +102,12 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     if ((int)blockIdx.y * 32 * TI >= a.Cout) return;      // a problem with fewer channel blocks than the widest of its group
     constexpr int BM = 32 * TI;   // output channels per workgroup
     constexpr int BN = 16 * TJ * NWN;   // pixels per workgroup
-    constexpr int LD = 80;        // bytes per LDS row: 64 + 16 pad (conflict-free ds_read_b128 of 16 rows)
+    // 64-byte LDS rows (one K step of a channel / pixel), the four 16-byte chunks of row r stored at chunk position c ^ f(r),
+    // f = {0, 2, 3, 1}[(r >> 2) & 3]: ds_read_b128 serves a wave in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... and
+    // with this f the 16 rows x chunks of every group fall on 16 different 16-byte bank slots. (The 80-byte padded rows of rounds 1-2
+    // were conflict-free for 16 consecutive lanes only: PMC counted 44 % conflict cycles.)
+    constexpr int LD = 64;
+    auto swz = [](int row, int chunk) { return chunk ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3); };
     constexpr int PGS = NTH / 16; // pixel groups of the staging role (16 channel quads x PGS pixels per pass)
     constexpr int PPT = BN / PGS; // pixels per thread when staging X
     constexpr int WPT = (BM * 4 + NTH - 1) / NTH;  // 16-byte weight chunks per thread
@@ -150,14 +155,17 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     const int cq = tid & 15, pg = tid >> 4;
     int poff[PPT];
     unsigned pmask[PPT];
+    int ho_i = (pix0 + pg) / a.Wo, wo_i = (pix0 + pg) - ho_i * a.Wo;      // one division; the thread's pixels are PGS apart
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int p = pix0 + pg + PGS * i;
         poff[i] = 0;
         pmask[i] = 0u;
+        const int ho = ho_i, wo = wo_i;
+        wo_i += PGS;
+        while (wo_i >= a.Wo) { wo_i -= a.Wo; ++ho_i; }
         if (p < L) {
-            const int ho = p / a.Wo;
-            const int h0 = ho * a.stride - a.pad, w0 = (p - ho * a.Wo) * a.stride - a.pad;
+            const int h0 = ho * a.stride - a.pad, w0 = wo * a.stride - a.pad;
             poff[i] = (h0 * a.W + w0) * a.in_ld + cq * 4;
             unsigned hm = 0u, wm = 0u;              // rows / columns of the window inside the image; mask = their outer product
             for (int k = 0; k < a.ks; ++k) {
@@ -217,11 +225,13 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
         constexpr bool CL = decltype(clamp_c)::value;
 #pragma unroll
         for (int i = 0; i < PPT; ++i)
-            *reinterpret_cast<int *>(Xbuf(buf) + (pg + PGS * i) * LD + cq * 4) = quant_pack4<CL>(st.xr[i], st.sr, st.rr, sx);
+            *reinterpret_cast<int *>(Xbuf(buf) + (pg + PGS * i) * LD + swz(pg + PGS * i, cq >> 2) * 16 + (cq & 3) * 4) =
+                quant_pack4<CL>(st.xr[i], st.sr, st.rr, sx);
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int item = tid + NTH * i;
-            if (BM * 4 % NTH == 0 || item < BM * 4) *reinterpret_cast<i32x4 *>(Wbuf(buf) + (item >> 2) * LD + (item & 3) * 16) = st.wreg[i];
+            if (BM * 4 % NTH == 0 || item < BM * 4)
+                *reinterpret_cast<i32x4 *>(Wbuf(buf) + (item >> 2) * LD + swz(item >> 2, item & 3) * 16) = st.wreg[i];
         }
     };
 
@@ -235,10 +245,10 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
         i32x4 af[TI], bf[TJ];
 #pragma unroll
         for (int i = 0; i < TI; ++i)
-            af[i] = *reinterpret_cast<const i32x4 *>(Wbuf(buf) + (wm * (BM / 2) + i * 16 + l15) * LD + g * 16);
+            af[i] = *reinterpret_cast<const i32x4 *>(Wbuf(buf) + (wm * (BM / 2) + i * 16 + l15) * LD + swz(l15, g) * 16);
 #pragma unroll
         for (int j = 0; j < TJ; ++j)
-            bf[j] = *reinterpret_cast<const i32x4 *>(Xbuf(buf) + (wn * (BN / NWN) + j * 16 + l15) * LD + g * 16);
+            bf[j] = *reinterpret_cast<const i32x4 *>(Xbuf(buf) + (wn * (BN / NWN) + j * 16 + l15) * LD + swz(l15, g) * 16);
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
@@ -252,8 +262,8 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
 #ifdef AQ3D_STAMPS
     unsigned long long t_fill_v = 0;
 #endif
+    load_step(stA, 0);          // issued before `clamp` (a global load itself) is needed to pick the loop variant
     auto k_loop = [&](auto clamp_c) {
-        load_step(stA, 0);
         store_step(clamp_c, stA, 0);
         __syncthreads();
 #ifdef AQ3D_STAMPS
@@ -827,6 +837,24 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
                 }
         }
     };
+    // epilogue operands of the lane's row quads, fetched before the K loop (it has 4-8 steps: a global round trip at the tail shows)
+    const bool vec4 = ((a.Cout | a.out_ld | a.out_coff | a.rows_total) & 3) == 0;      // wave-uniform
+    f32x4 e_b[TI], e_ps[TI], e_pt[TI], e_om[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        e_b[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; e_pt[i] = e_b[i];
+        e_ps[i] = (f32x4){1.f, 1.f, 1.f, 1.f}; e_om[i] = e_ps[i];
+        const int rbase = row0 + wm * TI * 16 + i * 16 + 4 * g;
+        if (vec4 && rbase < a.rows_total) {
+            const int oc = a.deconv > 0 ? rbase % a.Cout : rbase;
+            if (SQ) e_om[i] = *reinterpret_cast<const f32x4 *>(a.out_mul + oc);
+            if (a.bias) e_b[i] = *reinterpret_cast<const f32x4 *>(a.bias + oc);
+            if (a.post_scale) {
+                e_ps[i] = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
+                e_pt[i] = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
+            }
+        }
+    }
     load_step(0);
     store_step(0);
     __syncthreads();
@@ -844,8 +872,9 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
     // instead of four scalar ones, bias / BN loaded as vectors. (The deblocks write 36 MB each; the K loop has 4-8 steps, so the
     // epilogue is a large part of the kernel.)
     const int d = a.deconv;
-    const bool vec4 = ((a.Cout | a.out_ld | a.out_coff | a.rows_total) & 3) == 0;      // wave-uniform
     const int OW = d > 0 ? a.Wo * d : a.Wo, OH = d > 0 ? a.Ho * d : a.Ho;
+    f32x4 vout[TI][TJ];                 // vec4 path: values kept in registers, stored AFTER the piece maxima are flushed
+    size_t vdst[TI][TJ];
     int ph_[TJ], pw_[TJ];
 #pragma unroll
     for (int j = 0; j < TJ; ++j) {
@@ -861,13 +890,7 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
             const int ij = d > 0 ? rbase / a.Cout : 0;
             const int oc = rbase - ij * a.Cout;
             const int di = d > 0 ? ij / d : 0, dj = d > 0 ? ij - di * d : 0;
-            f32x4 b = (f32x4){0.f, 0.f, 0.f, 0.f}, ps = (f32x4){1.f, 1.f, 1.f, 1.f}, pt = b, om = ps;
-            if (SQ) om = *reinterpret_cast<const f32x4 *>(a.out_mul + oc);
-            if (a.bias) b = *reinterpret_cast<const f32x4 *>(a.bias + oc);
-            if (a.post_scale) {
-                ps = *reinterpret_cast<const f32x4 *>(a.post_scale + oc);
-                pt = *reinterpret_cast<const f32x4 *>(a.post_shift + oc);
-            }
+            const f32x4 b = e_b[i], ps = e_ps[i], pt = e_pt[i], om = e_om[i];
             float mint[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
@@ -883,7 +906,8 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
                     if (a.relu) t = fmaxf(t, 0.f);
                     v[r] = t;
                 }
-                *reinterpret_cast<f32x4 *>(a.y + ((size_t)oh * OW + ow) * a.out_ld + a.out_coff + oc) = v;
+                vout[i][j] = v;
+                vdst[i][j] = ((size_t)oh * OW + ow) * a.out_ld + a.out_coff + oc;
                 if (a.pieces_out) {
                     if (a.pieces_mode == 1 && oh > 0 && oh < OH - 1 && ow > 0 && ow < OW - 1) {
 #pragma unroll
@@ -903,12 +927,12 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
                 // merged interior class (see conv2d_i8_kernel): max over the wave's 16 pixel lanes in registers, one LDS atomic per row
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float m = mint[r];
-                    m = fmaxf(m, __shfl_xor(m, 1, 64));
-                    m = fmaxf(m, __shfl_xor(m, 2, 64));
-                    m = fmaxf(m, __shfl_xor(m, 4, 64));
-                    m = fmaxf(m, __shfl_xor(m, 8, 64));
-                    if (l15 == 0 && m > 0.f) atomicMax(&pm[10 * BM + (rbase - row0) + r], __float_as_uint(m));
+                    float m = mint[r];      // DPP row reduction over the 16 pixel lanes (values >= 0), result in the row's last lane
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x111, 0xf, 0xf, true)));
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x112, 0xf, 0xf, true)));
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x114, 0xf, 0xf, true)));
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x118, 0xf, 0xf, true)));
+                    if (l15 == 15 && m > 0.f) atomicMax(&pm[10 * BM + (rbase - row0) + r], __float_as_uint(m));
                 }
             }
             continue;
@@ -955,6 +979,15 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
                 }
                 atomicMax(reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc * a.pieces_ld + a.out_coff + oc, v);
             }
+        }
+    }
+    if (vec4) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            if (row0 + wm * TI * 16 + i * 16 + 4 * g >= a.rows_total) continue;
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                if (ph_[j] >= 0) *reinterpret_cast<f32x4 *>(a.y + vdst[i][j]) = vout[i][j];
         }
     }
 }
