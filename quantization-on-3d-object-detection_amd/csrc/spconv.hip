@@ -243,7 +243,10 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpconvGroup grp) {
 // the latency. Products are exact in fp32; only the 2^-22 tail of each activation is dropped.
 typedef _Float16 sp_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 sp_f16x4 __attribute__((ext_vector_type(4)));
-template <int CIN, int COUT, int WR, int WC>
+// W32: fp32 weights (an un-quantised layer), split into fp16 hi | lo planes while staged, three MFMAs per product like
+// conv2d_f16s_kernel (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo; the lo*lo term, ~2^-22 relative, is dropped). The fp32 matrix pipe
+// (spconv_kernel) took 242 us for VoxelNeXt's one 128 -> 128 fp32 layer.
+template <int CIN, int COUT, int WR, int WC, bool W32 = false>
 __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
     const SpconvArgs a = grp.p[blockIdx.y];
     constexpr int TM = 16 * WR;
@@ -257,7 +260,8 @@ __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
     _Float16 *Ah = reinterpret_cast<_Float16 *>(lds_raw);          // [TM][LDH]
     _Float16 *Al = Ah + TM * LDH;                                   // [TM][LDH]
     _Float16 *Bh = Al + TM * LDH;                                   // [COUT][LDH]
-    int *nbr_s = reinterpret_cast<int *>(Bh + COUT * LDH);          // [TM][kvol]
+    _Float16 *Bl = Bh + COUT * LDH;                                 // [COUT][LDH]  (W32 only)
+    int *nbr_s = reinterpret_cast<int *>(Bh + (W32 ? 2 : 1) * COUT * LDH);          // [TM][kvol]
     float *red = reinterpret_cast<float *>(nbr_s + TM * 27);        // [WR][COUT] abs-max partials
 
     const int tid = threadIdx.x;
@@ -303,8 +307,23 @@ __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
                 *reinterpret_cast<sp_f16x4 *>(Ah + r * LDH + c4 * 4) = h;
                 *reinterpret_cast<sp_f16x4 *>(Al + r * LDH + c4 * 4) = l;
             }
+            if (W32) {
+                const float *wk32 = static_cast<const float *>(a.weight) + (size_t)k * COUT * CIN;
+                for (int t = tid; t < COUT * C4; t += 256) {
+                    const int o = t / C4, c4 = t - o * C4;
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(wk32 + (size_t)o * CIN + c4 * 4);
+                    sp_f16x4 h, l;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        h[j] = (_Float16)v[j];
+                        l[j] = (_Float16)__fmul_rn(__fsub_rn(v[j], (float)h[j]), 2048.f);
+                    }
+                    *reinterpret_cast<sp_f16x4 *>(Bh + o * LDH + c4 * 4) = h;
+                    *reinterpret_cast<sp_f16x4 *>(Bl + o * LDH + c4 * 4) = l;
+                }
+            }
             const int8_t *wk = static_cast<const int8_t *>(a.weight) + (size_t)k * COUT * CIN;
-            for (int t = tid; t < COUT * C16; t += 256) {
+            for (int t = tid; !W32 && t < COUT * C16; t += 256) {
                 const int o = t / C16, c16 = t - o * C16;
                 const int4 q = *reinterpret_cast<const int4 *>(wk + (size_t)o * CIN + c16 * 16);
                 const int w[4] = {q.x, q.y, q.z, q.w};
@@ -337,6 +356,10 @@ __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
                     const sp_f16x8 fb = *reinterpret_cast<const sp_f16x8 *>(bh + nt * 16 * LDH + kc);
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, fb, acc[nt], 0, 0, 0);
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, fb, acc[nt], 0, 0, 0);
+                    if (W32) {
+                        const sp_f16x8 fbl = *reinterpret_cast<const sp_f16x8 *>(bh + COUT * LDH + nt * 16 * LDH + kc) * lo_scale;
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, fbl, acc[nt], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -404,7 +427,7 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
         if (f16w && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_I8 && a.cin == CIN_PAD) {
             bool same = true;
             for (int i = 1; i < n; ++i) same = same && grp.p[i].cin == CIN_PAD;
-            if (same && COUT == 128 && CIN_PAD == 128) {     // 64-row tiles (4 x 1 waves): the weights are re-streamed per tile (125 -> 100 us)
+            if constexpr (COUT == 128 && CIN_PAD == 128) if (same) {     // 64-row tiles (4 x 1 waves): the weights are re-streamed per tile (125 -> 100 us)
                 constexpr int TM2 = 64;
                 constexpr size_t lds3 = (size_t)(2 * TM2 + COUT) * (CIN_PAD + 8) * 2 + (size_t)TM2 * 27 * 4 + (size_t)4 * COUT * 4;
                 const int tiles2 = aq3d_div_up(a.cap_out, TM2);
@@ -422,6 +445,23 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
                 if (lds2 > 64 * 1024)
                     hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
                 hipLaunchKernelGGL(kern, dim3(grid, n), dim3(256), lds2, stream, grp);
+                AQ3D_CHECK_LAUNCH("aq3d_spconv");
+                return AQ3D_OK;
+            }
+        }
+    }
+    if constexpr (CIN_PAD == 128 && COUT == 128) {
+        if (act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && a.cin == CIN_PAD) {      // un-quantised 128 -> 128 layer: fp16 pipe, split operands
+            bool same = true;
+            for (int i = 1; i < n; ++i) same = same && grp.p[i].cin == CIN_PAD;
+            if (same) {
+                constexpr int TM2 = 64;
+                constexpr size_t lds3 = (size_t)(2 * TM2 + 2 * COUT) * (CIN_PAD + 8) * 2 + (size_t)TM2 * 27 * 4 + (size_t)4 * COUT * 4;
+                const int tiles2 = aq3d_div_up(a.cap_out, TM2);
+                const int grid2 = tiles2 < 2048 ? (tiles2 < 1 ? 1 : tiles2) : 2048;
+                auto kern = spconv_f16w_kernel<CIN_PAD, COUT, 4, 1, true>;
+                hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                hipLaunchKernelGGL(kern, dim3(grid2, n), dim3(256), lds3, stream, grp);
                 AQ3D_CHECK_LAUNCH("aq3d_spconv");
                 return AQ3D_OK;
             }
