@@ -39,9 +39,10 @@ class Detector3DTemplate(nn.Module):
         self._main_stream = None
         self._ev_prev_main = None
         self._rr = 0
-        # device plans of forward_async for un-split plans (VoxelNeXt): 1 plan 212, 2 plans 262 frames/s; bit-reproducible since the
-        # library is built without packed-fp32 instructions. Split plans (CenterPoint) use max(4, this).
-        self.async_streams = int(os.environ.get("AQ3D_STREAMS", "2"))
+        # device plans of forward_async: four for CenterPoint (split plans; 2 plans 503, 4 plans 555, 6 plans 516 frames/s in round 1)
+        # and for VoxelNeXt (un-split plans, captured without the in-graph index-stream fork: 2 plans 447, 3 plans 534, 4 plans 552
+        # frames/s); bit-reproducible since the library is built without packed-fp32 instructions.
+        self.async_streams = int(os.environ.get("AQ3D_STREAMS", "4"))
         self.max_batch_size = 1          # engine buffers are sized for this many frames per forward
         self.voxel_capacity = None       # rows of the sparse buffers (default MAX_NUMBER_OF_VOXELS * max_batch_size)
         self.voxelize_on_device = True   # False: consume batch_dict['voxels'/'voxel_coords'] when present
@@ -239,11 +240,18 @@ class Detector3DTemplate(nn.Module):
             n = max(1, int(os.environ["AQ3D_ASYNC_ENGINES"]))
         while len(self._extra_engines) < n - 1:
             self._extra_engines.append(Engine(self, primary.device))
-        for e in [primary] + self._extra_engines:
+        # Streams are bound to one of GPU_MAX_HW_QUEUES = 8 hardware queues in creation order: the streams that carry whole graphs
+        # (one per plan: index phase of a split plan / the whole frame of an un-split one) come first, then the main-phase streams of
+        # split plans; an un-split plan takes ONE stream (with a second, unused one per plan VoxelNeXt's four plans shared queues:
+        # 458 against 552 frames/s).
+        engines = [primary] + self._extra_engines
+        for e in engines:
             if getattr(e, "stream", None) is None:
                 e.stream = self._next_stream(primary.device)        # index phase (split plans) / whole frame (others)
-                e.main_stream = self._next_stream(primary.device)
                 e.ev_in, e.ev_idx, e.ev_free = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        for e in engines:
+            if getattr(e, "main_stream", None) is None:
+                e.main_stream = self._next_stream(primary.device) if e.split_index else e.stream
         if self._main_stream is None:
             self._main_stream = self._next_stream(primary.device)
         k = self._rr % n

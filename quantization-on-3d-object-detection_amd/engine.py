@@ -167,12 +167,11 @@ class Engine:
         self._graphs, self._pts_buf, self._pts_n, self._warm, self._calibrating = {}, None, 0, 0, None
         self.host_counts = torch.zeros(tuple(self.det_counts.shape), dtype=i32).pin_memory() if device.type == "cuda" else None
         self._ev_done = [torch.cuda.Event() for _ in range(self.NSLOT)] if device.type == "cuda" else None
-        # second HIP stream for the index (rulebook) chain, see _run_steps; AQ3D_INDEX_STREAM=0 keeps everything on one stream
+        # Round 1 ran the index (rulebook) chain of an un-split plan on a second stream forked INSIDE the frame: in a captured graph
+        # that is a parallel branch, and parallel graph branches take the hardware queues the other plans' graphs need — VoxelNeXt
+        # ran its frames in flight one after the other because of it (331 frames/s with the fork, 447 without on two plans, 552 on
+        # four; single-frame latency 3.00 -> 3.13 ms). Un-split plans are linear now.
         self.index_stream = None
-        if device.type == "cuda" and os.environ.get("AQ3D_INDEX_STREAM", "1") != "0" and not self.split_index:
-            self.index_stream = det._next_stream(device) if hasattr(det, "_next_stream") else torch.cuda.Stream(device=device)
-            self._ev_main = torch.cuda.Event()
-            self._ev_idx = [torch.cuda.Event() for _ in range(16)]
 
     # ------------------------------------------------------------------ helpers
     def _dev(self, arr, dtype=None):
@@ -1174,8 +1173,7 @@ class Engine:
         events: the index stream waits for whatever the main stream produced for it (voxelizer, bev_merge), the main stream
         waits for the newest index event before the next kernel that might read a gather table."""
         main = torch.cuda.current_stream(self.device)
-        # no fork without index steps (main phase of a split plan): an un-joined side stream must not enter a capture
-        side = self.index_stream if any(k in self.INDEX_KINDS for k, _ in steps) else None
+        side = self.index_stream if any(k in self.INDEX_KINDS for k, _ in steps) else None       # always None since round 2 (see __init__)
         pending = None        # newest event recorded on the index stream that main has not waited for yet
         if side is not None:
             self._ev_main.record(main)      # everything enqueued so far on main (voxelizer / arena clear)
