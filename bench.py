@@ -327,7 +327,7 @@ def main():
     dominant = max(warm.items(), key=lambda kv: kv[1][1])[0] if warm else None
 
     if args.inflight <= 0:
-        args.inflight = max(4, int(model.async_streams)) if getattr(eng, "split_index", False) else max(1, int(model.async_streams))
+        args.inflight = max(1, int(model.async_streams))
 
     def run_pipelined(n_steps, get_batch, stamps=None):
         n_det = 0

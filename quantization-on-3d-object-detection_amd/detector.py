@@ -36,8 +36,6 @@ class Detector3DTemplate(nn.Module):
                                 "point_head", "roi_head"]
         self._engine = None
         self._extra_engines = []         # forward_async: further device plans, each on its own HIP stream (see async_streams)
-        self._main_stream = None
-        self._ev_prev_main = None
         self._rr = 0
         # device plans of forward_async: four for CenterPoint (split plans; 2 plans 503, 4 plans 555, 6 plans 516 frames/s in round 1)
         # and for VoxelNeXt (un-split plans, captured without the in-graph index-stream fork: 2 plans 447, 3 plans 534, 4 plans 552
@@ -151,7 +149,6 @@ class Detector3DTemplate(nn.Module):
     def invalidate_engine(self):
         self._engine = None
         self._extra_engines = []
-        self._main_stream = None
         self._stream_next = 0            # the next plans take the SAME HIP streams again (see _next_stream)
 
     def _next_stream(self, device):
@@ -229,31 +226,20 @@ class Detector3DTemplate(nn.Module):
         return self._engine
 
     def _async_engine(self):
-        """Round-robin over the device plans of forward_async. A split plan (CenterPoint) gets four of them by default (measured:
-        2 plans 503, 4 plans 555, 6 plans 516, 8 plans 486 frames/s with one hardware queue per stream), each
-        with its own buffers and index-phase stream: the index phase of frame N+1 (voxelizer + rulebook, latency-bound, on the
-        critical path at the head of a frame) runs beside the dense phase of frame N, and the main phases of the frames in flight
-        overlap as well (see forward_async). One frame per plan is in flight at any time."""
+        """Round-robin over the device plans of forward_async: four by default (CenterPoint: 3 plans 712, 4 plans 757, 5 plans 636,
+        6 plans 659 frames/s; VoxelNeXt: 2 plans 447, 4 plans 552, 6 plans 500), each with its own buffers and ONE HIP stream that
+        carries the frame's hipGraph. One frame per plan is in flight at any time; nothing orders the frames of different plans
+        against each other — a frame's kernels are latency chains with tile-quantisation tails, and the other frames' kernels fill
+        what they leave idle."""
         primary = self.engine()
-        n = max(1, int(self.async_streams)) if not primary.split_index else max(4, int(self.async_streams))
-        if os.environ.get("AQ3D_ASYNC_ENGINES"):
-            n = max(1, int(os.environ["AQ3D_ASYNC_ENGINES"]))
+        n = max(1, int(self.async_streams))
         while len(self._extra_engines) < n - 1:
             self._extra_engines.append(Engine(self, primary.device))
-        # Streams are bound to one of GPU_MAX_HW_QUEUES = 8 hardware queues in creation order: the streams that carry whole graphs
-        # (one per plan: index phase of a split plan / the whole frame of an un-split one) come first, then the main-phase streams of
-        # split plans; an un-split plan takes ONE stream (with a second, unused one per plan VoxelNeXt's four plans shared queues:
-        # 458 against 552 frames/s).
-        engines = [primary] + self._extra_engines
-        for e in engines:
+        # streams are bound to one of GPU_MAX_HW_QUEUES = 8 hardware queues in creation order: nothing but the plans' streams is created
+        for e in [primary] + self._extra_engines:
             if getattr(e, "stream", None) is None:
-                e.stream = self._next_stream(primary.device)        # index phase (split plans) / whole frame (others)
-                e.ev_in, e.ev_idx, e.ev_free = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
-        for e in engines:
-            if getattr(e, "main_stream", None) is None:
-                e.main_stream = self._next_stream(primary.device) if e.split_index else e.stream
-        if self._main_stream is None:
-            self._main_stream = self._next_stream(primary.device)
+                e.stream = self._next_stream(primary.device)
+                e.ev_in = torch.cuda.Event()
         k = self._rr % n
         self._rr += 1
         return primary if k == 0 else self._extra_engines[k - 1]
@@ -303,13 +289,10 @@ class CenterPoint(Detector3DTemplate):
         if B > self.max_batch_size:
             self.max_batch_size = B
         eng = self.engine()
-        if self._main_stream is not None:       # frames still in flight from forward_async use this plan's buffers
-            cur = torch.cuda.current_stream(eng.device)
-            cur.wait_stream(self._main_stream)
-            for e in [eng] + self._extra_engines:
-                if getattr(e, "stream", None) is not None:
-                    cur.wait_stream(e.stream)
-                    cur.wait_stream(e.main_stream)
+        cur = torch.cuda.current_stream(eng.device)     # frames still in flight from forward_async use the plans' buffers
+        for e in [eng] + self._extra_engines:
+            if getattr(e, "stream", None) is not None:
+                cur.wait_stream(e.stream)
         eng.run(batch_dict)
         batch_dict["final_box_dicts"] = eng.collect(B)
         return self.post_processing(batch_dict)
@@ -330,30 +313,9 @@ class CenterPoint(Detector3DTemplate):
         eng._ev_done[eng.slot].synchronize()
         caller = torch.cuda.current_stream(eng.device)
         eng.ev_in.record(caller)                                   # the inputs were produced on the caller's stream
-        if eng.split_index:
-            Bf = eng.begin(batch_dict)
-            eng.stream.wait_event(eng.ev_in)
-            eng.stream.wait_event(eng.ev_free)                     # this plan's previous frame is done with its index buffers
-            with torch.cuda.stream(eng.stream):
-                eng.run_index(batch_dict, Bf)
-                eng.ev_idx.record(eng.stream)
-            # main phases run one after the other, each on its own plan's main stream, chained by events
-            ms = eng.main_stream
-            ms.wait_event(eng.ev_idx)
-            # The main phases of consecutive frames run on different plans and are NOT ordered against each other: a frame's
-            # kernels are latency chains with tile-quantisation tails (274 tiles on 256 CUs ...), and the other frame's kernels
-            # fill what they leave idle — 384 → 503 frames/s at two frames in flight, 555 at four. AQ3D_MAIN_OVERLAP=0 chains them
-            # (lowest single-frame latency).
-            if self._ev_prev_main is not None and os.environ.get("AQ3D_MAIN_OVERLAP", "1") == "0":
-                ms.wait_event(self._ev_prev_main)
-            with torch.cuda.stream(ms):
-                eng.run_main(Bf)
-                eng.ev_free.record(ms)
-            self._ev_prev_main = eng.ev_free
-        else:
-            eng.stream.wait_event(eng.ev_in)
-            with torch.cuda.stream(eng.stream):
-                eng.run(batch_dict)
+        eng.stream.wait_event(eng.ev_in)
+        with torch.cuda.stream(eng.stream):
+            eng.run(batch_dict)
         return PendingFrame(self, eng, eng.slot, B, batch_dict)
 
     def post_processing(self, batch_dict):

@@ -147,13 +147,12 @@ class Engine:
             self._build_sparse(det.backbone_3d)
             self._build_dense(det.backbone_2d, det.dense_head)
         self.arena.finalize()
-        # split plan: the index chain (incl. the voxelizer) is a phase of its own that forward_async runs a frame ahead on a
-        # second stream; VoxelNeXt's bev_merge makes later index steps depend on features, so its plan stays in one piece
-        self.split_index = not self.fully_sparse
-        self.index_steps = [st for st in self.steps if st[0] in self.INDEX_KINDS] if self.split_index else []
-        self.main_steps = [st for st in self.steps if st[0] not in self.INDEX_KINDS] if self.split_index else list(self.steps)
+        # A frame is ONE linear launch plan (voxelizer, index chain, sparse convs, BEV, head, decode) = one captured hipGraph on one
+        # stream. Rounds 1-2 ran CenterPoint's index chain as a phase of its own on a second stream, one frame ahead: with the
+        # kernels of the end of round 2 four linear plans deliver 757 frames/s against 649 for four split ones (and 2.38 against
+        # 2.42 ms single-frame latency) — fewer streams for the same number of frames in flight, each with its own hardware queue.
         self._graph_now = self._warm_now = False
-        self._index_batch = self._static_batch = None
+        self._static_batch = None
         self.slot = 0
         self.slot_generation = [0] * self.NSLOT
         self.use_graph = device.type == "cuda" and os.environ.get("AQ3D_GRAPH", "1") != "0"
@@ -167,11 +166,9 @@ class Engine:
         self._graphs, self._pts_buf, self._pts_n, self._warm, self._calibrating = {}, None, 0, 0, None
         self.host_counts = torch.zeros(tuple(self.det_counts.shape), dtype=i32).pin_memory() if device.type == "cuda" else None
         self._ev_done = [torch.cuda.Event() for _ in range(self.NSLOT)] if device.type == "cuda" else None
-        # Round 1 ran the index (rulebook) chain of an un-split plan on a second stream forked INSIDE the frame: in a captured graph
-        # that is a parallel branch, and parallel graph branches take the hardware queues the other plans' graphs need — VoxelNeXt
-        # ran its frames in flight one after the other because of it (331 frames/s with the fork, 447 without on two plans, 552 on
-        # four; single-frame latency 3.00 -> 3.13 ms). Un-split plans are linear now.
-        self.index_stream = None
+        # (Round 1 ran the index chain on a second stream forked inside the frame: in a captured graph that is a parallel branch, and
+        # parallel graph branches take the hardware queues the other plans' graphs need — VoxelNeXt's frames in flight ran one after
+        # the other because of it: 331 frames/s with the fork, 552 without on four plans. Frames are linear now.)
 
     # ------------------------------------------------------------------ helpers
     def _dev(self, arr, dtype=None):
@@ -1043,17 +1040,20 @@ class Engine:
         return B
 
     def run(self, batch_dict):
-        """Enqueue one batch on the current stream (index phase, then main phase). Results sit in self.heads[*]['out_*'] and
-        self.det_counts (slot self.slot). Detector.forward_async drives the two phases on different streams instead."""
+        """Enqueue one batch on the current stream. Results sit in self.heads[*]['out_*'] and self.det_counts (slot self.slot);
+        Detector.forward_async calls this on the plan's own stream."""
         B = self.begin(batch_dict)
-        self.run_index(batch_dict, B)
-        self.run_main(B)
+        if self._graph_now:
+            batch_dict = self._stage_points(batch_dict)
+            self._static_batch = batch_dict
+        self._phase(("all", self.slot), lambda: self._enqueue(batch_dict, B))
+        self._publish()
         return B
 
     def begin(self, batch_dict):
-        """Per-frame bookkeeping: picks the result slot and whether this frame replays captured hipGraphs (single-sample
-        frames given as raw points: one host call per phase instead of ~180 launches — the eager path is host-bound at
-        ~18 us per Python launch) or is enqueued eagerly (timers, calibration, batches, pre-voxelized input)."""
+        """Per-frame bookkeeping: picks the result slot and whether this frame replays its captured hipGraph (single-sample
+        frames given as raw points: one host call instead of ~180 launches — the eager path is host-bound at ~18 us per Python
+        launch) or is enqueued eagerly (timers, calibration, batches, pre-voxelized input)."""
         B = int(batch_dict["batch_size"])
         if B > self.batch_cap:
             raise ValueError("batch_size %d exceeds the engine's max_batch_size %d" % (B, self.batch_cap))
@@ -1064,26 +1064,6 @@ class Engine:
         if self._warm_now:
             self._warm += 1
         return B
-
-    def run_index(self, batch_dict, B):
-        """Phase 1 — everything that depends on the point coordinates only: voxelizer + the whole index chain (hash tables,
-        gather tables, strided output sets). In a split plan it runs on its own stream one frame AHEAD of phase 2."""
-        if self._graph_now:
-            batch_dict = self._stage_points(batch_dict)
-            self._static_batch = batch_dict
-        if not self.split_index:
-            self._index_batch = batch_dict      # un-split plans (VoxelNeXt: bev_merge feeds later index steps) voxelize in phase 2
-            return
-        self._phase("idx", lambda: self._enqueue_index(batch_dict, B))
-
-    def run_main(self, B):
-        """Phase 2 — features: sparse convs, BEV backbone, head, decode, NMS; then the stream-ordered result read-back."""
-        if self.split_index:
-            self._phase(("main", self.slot), lambda: self._enqueue_main(B))
-        else:
-            bd = self._index_batch
-            self._phase(("all", self.slot), lambda: self._enqueue(bd, B))
-        self._publish()
 
     def _phase(self, key, enqueue):
         if self._graph_now and not self._warm_now and self.use_graph:
@@ -1111,16 +1091,6 @@ class Engine:
         with _Timed(self, "voxelize"):
             self._voxelize(batch_dict, B)
         self._run_steps(self.steps, B)
-
-    def _enqueue_index(self, batch_dict, B):
-        with _Timed(self, "voxelize"):
-            self._voxelize(batch_dict, B)
-        for kind, arg in self.index_steps:
-            self._run_index(kind, arg)
-
-    def _enqueue_main(self, B):
-        self.arena.clear()
-        self._run_steps(self.main_steps, B)
 
     # ------------------------------------------------------------------ hipGraph replay
     def _graph_ok(self, batch_dict, B):
@@ -1167,30 +1137,11 @@ class Engine:
     INDEX_KINDS = ("index_subm", "index_down", "index_head")
 
     def _run_steps(self, steps, B):
-        """Walks the plan. Index generation (hash tables, gather tables, strided output sets) depends only on voxel
-        coordinates, never on features, so it runs on its own HIP stream ahead of the convolutions that consume it: the small
-        latency-bound rulebook kernels execute beside the previous level's convs instead of between them. Ordering is by
-        events: the index stream waits for whatever the main stream produced for it (voxelizer, bev_merge), the main stream
-        waits for the newest index event before the next kernel that might read a gather table."""
-        main = torch.cuda.current_stream(self.device)
-        side = self.index_stream if any(k in self.INDEX_KINDS for k, _ in steps) else None       # always None since round 2 (see __init__)
-        pending = None        # newest event recorded on the index stream that main has not waited for yet
-        if side is not None:
-            self._ev_main.record(main)      # everything enqueued so far on main (voxelizer / arena clear)
-            side.wait_event(self._ev_main)
+        """Walks the plan in order on the current stream."""
         for si, (kind, arg) in enumerate(steps):
             if kind in self.INDEX_KINDS:
-                if side is None:
-                    self._run_index(kind, arg)
-                else:
-                    with torch.cuda.stream(side):
-                        self._run_index(kind, arg)
-                        pending = self._ev_idx[si % len(self._ev_idx)]
-                        pending.record(side)
+                self._run_index(kind, arg)
                 continue
-            if pending is not None:
-                main.wait_event(pending)
-                pending = None
             if kind == "spconv":
                 self._run_spconv(arg)
             elif kind == "conv2d":
@@ -1214,14 +1165,9 @@ class Engine:
             elif kind == "bev_merge":
                 with _Timed(self, "rulebook"):
                     self._bev_merge()
-                if side is not None:            # the merged site set feeds the index steps that follow
-                    self._ev_main.record(main)
-                    side.wait_event(self._ev_main)
             elif kind == "voxel_decode_nms":
                 with _Timed(self, "decode_nms"):
                     self._voxel_decode_nms()
-        if pending is not None:
-            main.wait_event(pending)
 
     def _run_index(self, kind, arg):
         if kind == "index_subm":

@@ -8,7 +8,7 @@ from amdq3d.datasets import load_data_to_gpu
 dev = torch.device("cuda:0")
 cfgp, npts, nvox, _ = bench.WORKLOADS["voxelnext"]
 cfg, ds, model, state = bench.build(cfgp, dev, npts, nvox)
-model.async_streams = 2
+model.async_streams = 4
 NF = 8
 batches = []
 for i in range(NF):

@@ -92,7 +92,7 @@ def test_graph_replay_survives_later_allocations_and_a_second_plan(dev):
     with torch.no_grad():
         got = [_np(model(_batch(ds, i, dev))[0][0]) for i in range(2)]
     assert all(_same(r, g) for r, g in zip(ref, got))
-    # pipelined: four frames in flight on four device plans (index phase a frame ahead, main phases overlapping)
+    # pipelined: four frames in flight on four device plans (one linear hipGraph per frame, nothing orders the plans against each other)
     import collections
     with torch.no_grad():
         pend, outs = collections.deque(), []
@@ -102,29 +102,24 @@ def test_graph_replay_survives_later_allocations_and_a_second_plan(dev):
                 outs.append(_np(pend.popleft().result()[0][0]))
         while pend:
             outs.append(_np(pend.popleft().result()[0][0]))
-    assert len(model._extra_engines) == 3 and all("idx" in e._graphs for e in [model._engine] + model._extra_engines)
+    assert len(model._extra_engines) == 3 and all(len(e._graphs) >= 1 for e in [model._engine] + model._extra_engines)
     for i, o in enumerate(outs):
         assert _same(ref[i % 2], o), "pipelined frame %d differs" % i
     del junk
 
 
-@pytest.mark.parametrize("env", ["AQ3D_NO_GROUPS", "AQ3D_INDEX_STREAM"])
-def test_grouped_launches_and_index_stream_do_not_change_results(dev, env, monkeypatch):
-    """nuScenes 6-head model: 36 first convs + 36 final convs go out as grouped launches; the rulebook runs on its own stream."""
+def test_grouped_launches_do_not_change_results(dev, monkeypatch):
+    """nuScenes 6-head model: 36 first convs + 36 final convs go out as grouped launches; same detections as one launch per conv."""
     ds, model = _model("nuscenes")
     with torch.no_grad():
         base = _np(model(_batch(ds, 0, dev))[0][0])
     n_groups = sum(1 for k, _ in model.engine().steps if k == "conv2d_group")
     assert n_groups >= 2
-    monkeypatch.setenv(env, "0" if env == "AQ3D_INDEX_STREAM" else "1")
+    monkeypatch.setenv("AQ3D_NO_GROUPS", "1")
     model._engine = None            # rebuild the plan under the switch
     with torch.no_grad():
         other = _np(model(_batch(ds, 0, dev))[0][0])
-    eng = model.engine()
-    if env == "AQ3D_NO_GROUPS":
-        assert not any(k == "conv2d_group" for k, _ in eng.steps)
-    else:
-        assert eng.index_stream is None
+    assert not any(k == "conv2d_group" for k, _ in model.engine().steps)
     assert _same(base, other)
 
 
@@ -148,8 +143,8 @@ def test_runtime_started_before_import_means_eager_launches():
 def test_stale_pending_frame_raises_and_weight_load_rebuilds_the_plan(dev, monkeypatch):
     """(i) a PendingFrame whose result slot was handed to a later frame must not silently return that frame's
     detections; (ii) nn.Module.load_state_dict after the first forward must not keep serving the old compiled weights."""
-    monkeypatch.setenv("AQ3D_ASYNC_ENGINES", "1")
     ds, model = _model(quantized=False)
+    model.async_streams = 1             # one plan: its NSLOT result slots wrap after NSLOT further frames
     from amdq3d.engine import Engine
     with torch.no_grad():
         first = model.forward_async(_batch(ds, 0, dev))
