@@ -148,9 +148,10 @@ class Engine:
             self._build_dense(det.backbone_2d, det.dense_head)
         self.arena.finalize()
         # A frame is ONE linear launch plan (voxelizer, index chain, sparse convs, BEV, head, decode) = one captured hipGraph on one
-        # stream. Rounds 1-2 ran CenterPoint's index chain as a phase of its own on a second stream, one frame ahead: with the
-        # kernels of the end of round 2 four linear plans deliver 757 frames/s against 649 for four split ones (and 2.38 against
-        # 2.42 ms single-frame latency) — fewer streams for the same number of frames in flight, each with its own hardware queue.
+        # stream. Rounds 1-2 ran CenterPoint's index chain as a phase of its own on a second stream, one frame ahead, and VoxelNeXt's
+        # on a stream forked inside the frame (a parallel branch of the captured graph): four linear plans deliver 757 frames/s
+        # against 649 for four split ones, VoxelNeXt 552 against 331 — parallel graph branches and second streams take the hardware
+        # queues the other plans' graphs need.
         self._graph_now = self._warm_now = False
         self._static_batch = None
         self.slot = 0
@@ -166,10 +167,6 @@ class Engine:
         self._graphs, self._pts_buf, self._pts_n, self._warm, self._calibrating = {}, None, 0, 0, None
         self.host_counts = torch.zeros(tuple(self.det_counts.shape), dtype=i32).pin_memory() if device.type == "cuda" else None
         self._ev_done = [torch.cuda.Event() for _ in range(self.NSLOT)] if device.type == "cuda" else None
-        # (Round 1 ran the index chain on a second stream forked inside the frame: in a captured graph that is a parallel branch, and
-        # parallel graph branches take the hardware queues the other plans' graphs need — VoxelNeXt's frames in flight ran one after
-        # the other because of it: 331 frames/s with the fork, 552 without on four plans. Frames are linear now.)
-
     # ------------------------------------------------------------------ helpers
     def _dev(self, arr, dtype=None):
         t = torch.from_numpy(np.ascontiguousarray(arr))
