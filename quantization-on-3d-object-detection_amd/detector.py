@@ -308,9 +308,10 @@ class CenterPoint(Detector3DTemplate):
         if B > self.max_batch_size:
             self.max_batch_size = B
         eng = self._async_engine()
-        # one frame in flight per plan: its previous frame has to be complete before its buffers are handed to the next one
-        # (pipelines deeper than the number of plans block here instead of racing; a completed event costs nothing)
-        eng._ev_done[eng.slot].synchronize()
+        # A plan's frames are ordered by its stream, so a second frame may be QUEUED behind the one that is running (the plan has
+        # NSLOT = 2 result slots); what has to be complete is the frame whose result slot this one takes over (pipelines deeper
+        # than NSLOT frames per plan block here instead of racing; a completed event costs nothing)
+        eng._ev_done[(eng.slot + 1) % eng.NSLOT].synchronize()
         caller = torch.cuda.current_stream(eng.device)
         eng.ev_in.record(caller)                                   # the inputs were produced on the caller's stream
         eng.stream.wait_event(eng.ev_in)
