@@ -105,6 +105,17 @@ def test_graph_replay_survives_later_allocations_and_a_second_plan(dev):
     assert len(model._extra_engines) == 3 and all(len(e._graphs) >= 1 for e in [model._engine] + model._extra_engines)
     for i, o in enumerate(outs):
         assert _same(ref[i % 2], o), "pipelined frame %d differs" % i
+    # eight in flight: every plan has a second frame queued behind the running one (NSLOT = 2 result slots per plan)
+    with torch.no_grad():
+        pend, outs = collections.deque(), []
+        for i in range(41):
+            pend.append(model.forward_async(_batch(ds, i % 2, dev)))
+            if len(pend) >= 8:
+                outs.append(_np(pend.popleft().result()[0][0]))
+        while pend:
+            outs.append(_np(pend.popleft().result()[0][0]))
+    for i, o in enumerate(outs):
+        assert _same(ref[i % 2], o), "frame %d of the 8-deep pipeline differs" % i
     del junk
 
 
