@@ -450,8 +450,8 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
             }
         }
     }
-    if constexpr (CIN_PAD == 128 && COUT == 128) {
-        if (act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && a.cin == CIN_PAD) {      // un-quantised 128 -> 128 layer: fp16 pipe, split operands
+    if constexpr (CIN_PAD == 128 && (COUT == 128 || COUT == 16)) {
+        if (act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && a.cin == CIN_PAD) {      // un-quantised 128 -> 128 / 128 -> 16 layers: fp16 pipe, split operands
             bool same = true;
             for (int i = 1; i < n; ++i) same = same && grp.p[i].cin == CIN_PAD;
             if (same) {
