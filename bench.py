@@ -59,7 +59,11 @@ def build(cfg_path, dev, n_points=N_POINTS, n_voxels=N_VOXELS, seed0=4, static=F
     init_synthetic_weights(model, 4)
     model.eval()
     state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    model.voxel_capacity = int(os.environ.get("AQ3D_VOXEL_CAP", "65536"))
+    # row capacities (printed in `config`): voxel level >= the frames' 30 000 / 20 000 voxels; every strided level 2.5 x that (the
+    # largest strided level of the 64 frames that ranks 0-7 run holds 66 132 rows, tests/test_host_cpu.py). A frame that outgrows
+    # a level raises — nothing is truncated silently.
+    model.voxel_capacity = int(os.environ.get("AQ3D_VOXEL_CAP", "40960"))
+    model.level_capacity_factor = float(os.environ.get("AQ3D_LEVEL_FACTOR", "2.5"))
     if cfg.MODEL.NAME == "VoxelNeXt":
         quant.dynamic_quant_voxelnext(model, 8, 8, sq=True)
     elif static:
@@ -413,6 +417,7 @@ def main():
                        "frames_per_rank": N_FRAMES, "frame_seeds": "4 + 8*rank + i", "points": n_points,
                        "voxels": n_voxels, "parallelism": "replicas(frames)x%d" % world, "world_size_seen_by_rccl": world_seen,
                        "avg_boxes_per_frame": n_det / max(args.steps, 1),
+                       "row_capacity_per_index_level": [lv["cap"] for lv in eng.levels],
                        "sparse_conv_weights": "one fp16 per product (layers <= 1e-3 of scale)" if args.sparse_fp16_weights
                        else "fp16 hi|lo pair (layers <= 2e-5 of scale)"},
             "roofline": roof,

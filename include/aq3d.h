@@ -15,9 +15,10 @@
  *   aq3d_voxelize            spconv Point2VoxelCPU3d.point_to_voxel as called from
  *                            pcdet/datasets/processor/data_processor.py:45-61 (+ MeanVFE, vfe/mean_vfe.py:25-29)
  *   aq3d_mean_vfe            pcdet/models/backbones_3d/vfe/mean_vfe.py:14-31
- *   aq3d_hash_build / aq3d_subm_neighbors / aq3d_conv_outputs
+ *   aq3d_level_from_points / aq3d_level_from_coords / aq3d_level_downsample / aq3d_level_neighbors
  *                            spconv.pytorch.SubMConv3d / SparseConv3d index generation, call sites
- *                            pcdet/models/backbones_3d/spconv_backbone.py:12-15,39-46,194-234
+ *                            pcdet/models/backbones_3d/spconv_backbone.py:12-15,39-46,194-234 (and the voxel generator fused
+ *                            with it for raw point input)
  *   aq3d_absmax_cols / aq3d_quantize_rows
  *                            pytorch_quantization TensorQuantizer(axis=1) as used in quant/quant.py:21-26,50-52
  *   aq3d_spconv              spconv gather-GEMM-scatter behind QConvNd.forward, quant/quant.py:36-58,
@@ -30,7 +31,7 @@
  *                            pcdet/models/dense_heads/center_head.py:22-29,75-82 (the layers left in fp32)
  *   aq3d_center_decode       centernet_utils.decode_bbox_from_heatmap, model_utils/centernet_utils.py:155-241
  *   aq3d_nms_rotated         iou3d_nms_utils.nms_gpu → iou3d_nms.cpp:137-183 + iou3d_nms_kernel.cu:295-339
- *   aq3d_bev_merge           VoxelResBackBone8xVoxelNeXt.bev_out, spconv_backbone_voxelnext.py:149-198
+ *   aq3d_level_merge(_sum)   VoxelResBackBone8xVoxelNeXt.bev_out, spconv_backbone_voxelnext.py:149-198
  *   aq3d_voxel_decode        centernet_utils.decode_bbox_from_voxels_nuscenes, model_utils/centernet_utils.py:243-354
  *   aq3d_boxes_iou3d / aq3d_recall_counts
  *                            iou3d_nms_utils.boxes_iou3d_gpu (iou3d_nms_utils.py:48-81, kernel iou3d_nms_kernel.cu:236-249) and
@@ -92,38 +93,74 @@ int aq3d_voxelize(const float *points, int32_t n_points, const aq3d_voxel_cfg *c
                   int32_t append, int32_t *coords_out, float *feats_out, int32_t *npts_out, int32_t *count_io,
                   int32_t cap, void *workspace, size_t workspace_bytes, void *stream);
 
-/* voxels f32 [m, P, C], num_points f32 or i32 [m] → feats f32 [m, C] = sum / max(num,1). */
+/* voxels f32 [m, P, C], num_points f32 [m] → feats f32 [*, C]: row row_of_voxel[v] (v itself when NULL; -1 skips the voxel)
+ * = sum / max(num,1). */
 int aq3d_mean_vfe(const float *voxels, const float *num_points, int32_t m, int32_t P, int32_t C,
-                  float *feats_out, void *stream);
+                  const int32_t *row_of_voxel, float *feats_out, void *stream);
 
-/* ---------------------------------------------------------------- sparse index generation ------ */
+/* ---------------------------------------------------------------- sparse index levels ---------- */
 
-/* A coordinate hash table is two arrays owned by the caller: keys i64 [table_size], vals i32 [table_size];
- * table_size is a power of two, >= 2 * capacity. */
+/* One index level = the set of active sites of one sparse tensor (what spconv keeps as SparseConvTensor.indices + its
+ * indice_dict). All arrays are device memory owned by the caller:
+ *   bits        u64 [aq3d_level_words(shape, batch)]  occupancy; word w <-> (b, z, y/8, x/8), bit (y%8)*8 + x%8
+ *   base        i32 [words]   number of sites in the words before w (raster rank of the word's first site)
+ *   row_of_rank i32 [cap]     raster rank -> row
+ *   coords      i32 [cap, 4]  rows (b, z, y, x)
+ *   count       i32 [1]       live rows = min(total[0], cap)
+ *   total       i32 [2]       [0] number of active sites (UNclamped: > cap means the level overflowed its buffers and the
+ *                             frame is invalid), [1] the largest per-sample number of sites
+ * Rows are numbered class by class (sites grouped by which planes of their 3x3x3 neighbourhood are occupied, heaviest
+ * class first, raster order inside a class) so that the 128-row tiles of the gather-GEMM kernels skip most kernel offsets. */
+typedef struct aq3d_level {
+    int32_t shape[3];          /* z, y, x */
+    int32_t batch;             /* samples (<= 64) */
+    int32_t cap;               /* row capacity */
+    int32_t reserved;
+    uint64_t *bits;
+    int32_t *base;
+    int32_t *row_of_rank;
+    int32_t *coords;
+    int32_t *count;
+    int32_t *total;
+} aq3d_level;
 
-/* Insert coords[0..*count) (rows b,z,y,x) → row index. shape = spatial shape (z, y, x). */
-int aq3d_hash_build(const int32_t *coords, const int32_t *count, int32_t cap, const int32_t shape[3],
-                    int64_t *table_keys, int32_t *table_vals, int32_t table_size, void *stream);
+int64_t aq3d_level_words(const int32_t shape[3], int32_t batch);
 
-/* Gather table of a submanifold conv: nbr[m][k] = row of the active site at coords[m] + (k - centre),
- * or -1.  k enumerates (kz, ky, kx) row-major; ksize odd. nbr is i32 [cap, kvol]. */
-int aq3d_subm_neighbors(const int32_t *coords, const int32_t *count, int32_t cap, const int32_t shape[3],
-                        const int32_t ksize[3], const int64_t *table_keys, const int32_t *table_vals,
-                        int32_t table_size, int32_t *nbr_out, void *stream);
+/* Scratch of the index builders below for levels of up to max_cap rows and max_words words and clouds of up to max_points
+ * points. The FIRST 256 BYTES must be zero before the first call (they hold self-resetting arrival counters); one
+ * workspace serves every call that is ordered on one stream. */
+size_t aq3d_index_workspace_bytes(int32_t max_cap, int64_t max_words, int32_t max_points);
 
-size_t aq3d_conv_outputs_workspace_bytes(int32_t cap_in, int32_t kvol, int32_t out_table_size);
+/* Hard voxelization + mean VFE straight into an index level (replaces spconv's Point2VoxelCPU3d.point_to_voxel as called
+ * from pcdet/datasets/processor/data_processor.py:45-61, + MeanVFE, vfe/mean_vfe.py:25-29, for the whole batch at once):
+ *   points f32 [n_points, cfg->point_stride]; with cfg->batch_col the sample index is column 0, else batch_index.
+ *   feats_out f32 [cap, C] mean of the first P points (in point order) of every voxel, npts_out i32 [cap] (may be NULL),
+ *   rows in the level's row order. cfg->max_voxels is NOT applied: level->total[1] > max_voxels tells the caller that the
+ *   reference would have dropped voxels (first-seen order) — aq3d_voxelize + aq3d_level_from_coords reproduce that case. */
+int aq3d_level_from_points(const float *points, int32_t n_points, const aq3d_voxel_cfg *cfg, int32_t batch_index,
+                           const aq3d_level *level, float *feats_out, int32_t *npts_out, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
-/* Active output set + gather table of a strided sparse conv.
- *   out site o is active iff some active input i = o*stride - pad + k exists (0 <= k < ksize).
- *   coords_out rows are produced in first-candidate order (input row major, then k).
- *   nbr_out i32 [cap_out, kvol]: input row feeding output row through kernel offset k, or -1.
- *   The input hash table (aq3d_hash_build of the inputs) must be valid; the output table is filled here. */
-int aq3d_conv_outputs(const int32_t *coords_in, const int32_t *count_in, int32_t cap_in,
-                      const int32_t shape_in[3], const int32_t ksize[3], const int32_t stride[3],
-                      const int32_t pad[3], const int64_t *in_keys, const int32_t *in_vals, int32_t in_table_size,
-                      int32_t *coords_out, int32_t *count_out, int32_t cap_out, int32_t *nbr_out,
-                      int64_t *out_keys, int32_t *out_vals, int32_t out_table_size,
-                      void *workspace, size_t workspace_bytes, void *stream);
+/* Level from given voxel coordinates (pcdet's pre-voxelized batch_dict: voxel_coords [n, 4] rows (b, z, y, x)).
+ * row_of_input i32 [n]: the row of input voxel i (-1: outside the grid). */
+int aq3d_level_from_coords(const int32_t *coords_in, int32_t n, const aq3d_level *level, int32_t *row_of_input,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* Active output set of a strided / dilating sparse conv (spconv SparseConv3d / SparseConv2d index generation):
+ * out site o is active iff some active input i = o*stride - pad + k exists (0 <= k < ksize). ksize 1..3, stride 1..2,
+ * pad 0..1 per axis; out->shape = (in + 2 pad - ksize) / stride + 1. */
+int aq3d_level_downsample(const aq3d_level *in, const int32_t ksize[3], const int32_t stride[3], const int32_t pad[3],
+                          const aq3d_level *out, void *workspace, size_t workspace_bytes, void *stream);
+
+/* One gather table: nbr i32 [out->cap, kvol], nbr[m][k] = row of `in` at coords_out[m] * stride - pad + k, or -1;
+ * k enumerates (kz, ky, kx) row-major. Submanifold conv: in == out, stride 1, pad = ksize / 2. */
+typedef struct aq3d_nbr_job {
+    const aq3d_level *in;
+    int32_t ksize[3], stride[3], pad[3];
+    int32_t *nbr;
+} aq3d_nbr_job;
+/* Up to 4 gather tables of one output level in ONE launch. */
+int aq3d_level_neighbors(const aq3d_level *out, const aq3d_nbr_job *jobs, int32_t n_jobs, void *stream);
 
 /* ---------------------------------------------------------------- sparse conv ----------------- */
 
@@ -381,21 +418,15 @@ int aq3d_decode_nms_batch(const aq3d_head_problem *heads, int32_t n, void *strea
 
 /* ---------------------------------------------------------------- VoxelNeXt (fully sparse) extras ---------------- */
 
-size_t aq3d_bev_merge_workspace_bytes(int32_t n_levels, int32_t cap_in, int32_t out_table_size);
-
 /* VoxelResBackBone8xVoxelNeXt.bev_out (pcdet/models/backbones_3d/spconv_backbone_voxelnext.py:149-198): union of up to 3
- * index levels projected onto the (y, x) plane — level l coordinates multiplied by scales[l] — with the features of
- * coinciding sites summed (fixed (level, z) order, no float atomics).
- *   coords/counts/feats/keys/vals/table_sizes: per level, host arrays of n_levels device pointers / sizes; every level has
- *   capacity cap_in, C channels and a valid 3-D hash table (aq3d_hash_build / aq3d_conv_outputs); shapes = [n_levels][3] (z,y,x).
- *   Output: coords_out i32 [cap_out,4] rows (b, 0, y, x) in first-candidate order, count_out, feats_out f32 [cap_out, C] and
- *   the 2-D hash table of the merged set (shape (1, H, W)) in out_keys / out_vals. */
-int aq3d_bev_merge(const int32_t *const *coords, const int32_t *const *counts, const float *const *feats,
-                   const int64_t *const *keys, const int32_t *const *vals, const int32_t *table_sizes,
-                   const int32_t *shapes, const int32_t *scales, int32_t n_levels, int32_t cap_in, int32_t C,
-                   int32_t H, int32_t W, int32_t *coords_out, int32_t *count_out, float *feats_out, int32_t cap_out,
-                   int64_t *out_keys, int32_t *out_vals, int32_t out_table_size, void *workspace, size_t workspace_bytes,
-                   void *stream);
+ * index levels projected onto the (y, x) plane — level l coordinates multiplied by scales[l] — as a 2-D level (shape (1, H, W)),
+ * and the features of coinciding sites summed in a fixed (level, z) order (no float atomics).
+ *   aq3d_level_merge      builds the merged level `out`;
+ *   aq3d_level_merge_sum  feats_out f32 [out->cap, C] from feats[l] f32 [levels[l]->cap, C]. */
+int aq3d_level_merge(const aq3d_level *const *levels, const int32_t *scales, int32_t n, const aq3d_level *out,
+                     void *workspace, size_t workspace_bytes, void *stream);
+int aq3d_level_merge_sum(const aq3d_level *const *levels, const float *const *feats, const int32_t *scales, int32_t n,
+                         int32_t C, const aq3d_level *out, float *feats_out, void *stream);
 
 /* centernet_utils.decode_bbox_from_voxels_nuscenes (model_utils/centernet_utils.py:243-354) for ONE sample: like
  * aq3d_center_decode, but the candidates are the *count live rows of a sparse head output (row-major maps with pixel

@@ -229,26 +229,28 @@ extern "C" int aq3d_voxelize(const float *points, int32_t n_points, const aq3d_v
 // ---- MeanVFE for pre-voxelized input (pcdet batch_dict 'voxels' / 'voxel_num_points') ----
 __global__ __launch_bounds__(VOX_BLOCK) void mean_vfe_kernel(const float *__restrict__ voxels,
                                                              const float *__restrict__ num_points, int m, int P, int C,
-                                                             float *__restrict__ out) {
+                                                             const int *__restrict__ row_of_voxel, float *__restrict__ out) {
     const int total = m * C;
     for (int t = blockIdx.x * VOX_BLOCK + threadIdx.x; t < total; t += gridDim.x * VOX_BLOCK) {
         int v = t / C, c = t - v * C;
+        const int row = row_of_voxel ? row_of_voxel[v] : v;
+        if (row < 0) continue;
         const float *src = voxels + (size_t)v * P * C + c;
         float acc = 0.f;
         for (int j = 0; j < P; ++j) acc = __fadd_rn(acc, src[(size_t)j * C]);
         float nrm = fmaxf(num_points[v], 1.0f);
-        out[t] = __fdiv_rn(acc, nrm);
+        out[(size_t)row * C + c] = __fdiv_rn(acc, nrm);
     }
 }
 
 extern "C" int aq3d_mean_vfe(const float *voxels, const float *num_points, int32_t m, int32_t P, int32_t C,
-                             float *feats_out, void *stream_) {
+                             const int32_t *row_of_voxel, float *feats_out, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     AQ3D_REQUIRE(m >= 0 && P >= 1 && C >= 1, "aq3d_mean_vfe: bad sizes m=%d P=%d C=%d", m, P, C);
     if (m == 0) return AQ3D_OK;
     AQ3D_REQUIRE(voxels && num_points && feats_out, "aq3d_mean_vfe: null argument");
     hipLaunchKernelGGL(mean_vfe_kernel, dim3(aq3d_grid((int64_t)m * C, VOX_BLOCK)), dim3(VOX_BLOCK), 0, stream, voxels,
-                       num_points, m, P, C, feats_out);
+                       num_points, m, P, C, row_of_voxel, feats_out);
     AQ3D_CHECK_LAUNCH("aq3d_mean_vfe");
     return AQ3D_OK;
 }

@@ -42,7 +42,11 @@ class Detector3DTemplate(nn.Module):
         # frames/s); bit-reproducible since the library is built without packed-fp32 instructions.
         self.async_streams = int(os.environ.get("AQ3D_STREAMS", "4"))
         self.max_batch_size = 1          # engine buffers are sized for this many frames per forward
-        self.voxel_capacity = None       # rows of the sparse buffers (default MAX_NUMBER_OF_VOXELS * max_batch_size)
+        self.voxel_capacity = None       # rows of the voxel level (default MAX_NUMBER_OF_VOXELS * max_batch_size)
+        # rows of every derived (strided / merged) index level: factor x voxel_capacity, never more than the level has cells, or the
+        # explicit {level index: rows}. A frame that outgrows a level RAISES ValueError (spconv would allocate more rows).
+        self.level_capacity_factor = 4.0
+        self.level_capacity = None
         self.voxelize_on_device = True   # False: consume batch_dict['voxels'/'voxel_coords'] when present
         # quantised sparse convs: False = weights as an fp16 hi|lo pair (two MFMAs per product, fp32-grade sums, every layer within
         # 2e-5 of the oracle); True = ONE fp16 weight per product (the north star's "int8 weights x fp16 activations" precision:

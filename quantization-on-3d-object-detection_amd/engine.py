@@ -130,12 +130,18 @@ class Engine:
         vcfg = proc["transform_points_to_voxels"]
         self.max_points_per_voxel = int(vcfg.MAX_POINTS_PER_VOXEL)
         self.max_voxels = int(vcfg.MAX_NUMBER_OF_VOXELS["test"])
+        # Row capacities. Level 0 (voxels): det.voxel_capacity or MAX_NUMBER_OF_VOXELS x batch. A strided level can hold up to
+        # prod(ceil(k / s)) = 8 times its input's sites (spconv sizes its outputs dynamically, spconv_backbone.py:230-231); its
+        # buffers get det.level_capacity_factor (4) x the level-0 capacity, never more than the level has cells, or what
+        # det.level_capacity = {level index: rows} says. A frame that outgrows a buffer RAISES (counts() / forward()).
         cap_opt = getattr(det, "voxel_capacity", None)
         self.cap = int(cap_opt) if cap_opt else self.max_voxels * self.batch_cap
+        self.level_factor = float(getattr(det, "level_capacity_factor", None) or 4.0)
+        self.level_caps = dict(getattr(det, "level_capacity", None) or {})
+        self._stats_pool = torch.zeros((32, 4), dtype=i32, device=device)      # per level: count, total, per-sample max, pad
         self.arena = _Arena(device)
         self.steps = []
         self.tensors = {}
-        self._voxel_ws = None
         self.sparse_fp16_weights = bool(getattr(det, "sparse_fp16_weights", False))
         self._head_args = {}
         self._force_rows = False     # teacher-forced tests: run the rows-only quantiser even where a producer epilogue does it
@@ -166,6 +172,8 @@ class Engine:
             self.use_graph = False
         self._graphs, self._pts_buf, self._pts_n, self._warm, self._calibrating = {}, None, 0, 0, None
         self.host_counts = torch.zeros(tuple(self.det_counts.shape), dtype=i32).pin_memory() if device.type == "cuda" else None
+        self.host_stats = torch.zeros((self.NSLOT,) + tuple(self._stats_pool.shape), dtype=i32).pin_memory() if device.type == "cuda" else None
+        self._slot_batch = [None] * self.NSLOT
         self._ev_done = [torch.cuda.Event() for _ in range(self.NSLOT)] if device.type == "cuda" else None
     # ------------------------------------------------------------------ helpers
     def _dev(self, arr, dtype=None):
@@ -175,23 +183,38 @@ class Engine:
         return t.to(self.device)
 
     # ------------------------------------------------------------------ sparse plan primitives
-    def _new_level(self, shape, kvol=27):
-        dev, cap = self.device, self.cap
-        lv = dict(shape=list(shape), coords=torch.zeros((cap, 4), dtype=i32, device=dev),
-                  count=torch.zeros((1,), dtype=i32, device=dev), table=ops.HashTable(cap, dev),
-                  nbr=torch.full((cap, kvol), -1, dtype=i32, device=dev), subm_ksize=(3, 3, 3))
+    def _level_cap(self, li, shape, bound=None):
+        """Row capacity of level li (see __init__): override, else min(cells, bound, factor x level-0 capacity)."""
+        if li in self.level_caps:
+            return int(self.level_caps[li])
+        if li == 0:
+            return self.cap
+        cells = int(np.prod(shape)) * self.batch_cap
+        cap = min(cells, int(np.ceil(self.level_factor * self.cap)))
+        if bound is not None:
+            cap = min(cap, int(bound))
+        return max(256, (cap + 255) // 256 * 256)
+
+    def _new_level(self, shape, kvol=27, bound=None):
+        dev = self.device
+        li = len(self.levels)
+        assert li < self._stats_pool.shape[0]
+        cap = self._level_cap(li, shape, bound)
+        ix = ops.IndexLevel(shape, self.batch_cap, cap, dev, stats=self._stats_pool[li])
+        lv = dict(shape=list(shape), cap=cap, index=ix, coords=ix.coords, count=ix.count,
+                  nbr=torch.full((cap, kvol), -1, dtype=i32, device=dev), subm_ksize=(3, 3, 3), jobs=None)
         self.levels.append(lv)
         return lv
 
     def _tensor(self, level, C, name):
-        return dict(buf=torch.zeros((self.cap, C), dtype=f32, device=self.device), C=C, level=level,
+        return dict(buf=torch.zeros((self.levels[level]["cap"], C), dtype=f32, device=self.device), C=C, level=level,
                     amax=self.arena.alloc(C), name=name)
 
     def _compile_spconv(self, mod, path, x, level_out, nbr, kvol, bn, relu, residual=None):
         """mod: SparseConvolution | QConvNd (w8a8, per input channel / per tensor) | QConv2d (weight-only).
         Returns the output tensor record. Output channels are padded to a multiple of 16 (MFMA tile), the pad
         columns carry zero weights / bias and unit BN scale."""
-        dev, cap = self.device, self.cap
+        dev, cap = self.device, self.levels[x["level"]]["cap"]     # codes / fake-quantised rows are the INPUT's rows
         q = mod if isinstance(mod, QConvNd) else None
         q2 = mod if isinstance(mod, QConv2d) else None
         conv = mod.module if (q is not None or q2 is not None) else mod
@@ -264,7 +287,7 @@ class Engine:
     def _compile_stages(self, bb, names):
         """conv_input + conv1 on level 0, then one strided SparseConv3d + residual blocks per named stage."""
         cap, dev = self.cap, self.device
-        self.levels = []          # dicts: shape, coords, count, table, nbr(subm), cap
+        self.levels = []          # dicts: shape, cap, index (ops.IndexLevel), coords, count, nbr (submanifold table), down
         self._new_level(list(bb.sparse_shape))
         C0 = self.num_point_features
         self.vfe_feats = torch.zeros((cap, C0), dtype=f32, device=dev)
@@ -287,7 +310,7 @@ class Engine:
             lv_in = self.levels[si]
             lv_out = self._new_level(ops.conv_out_shape(lv_in["shape"], conv.kernel_size, conv.stride, conv.padding))
             lv_out["down"] = dict(src=si, ksize=conv.kernel_size, stride=conv.stride, pad=conv.padding,
-                                  nbr=torch.full((cap, 27), -1, dtype=i32, device=dev))
+                                  nbr=torch.full((lv_out["cap"], 27), -1, dtype=i32, device=dev))
             self.steps.append(("index_down", si + 1))
             x = self._compile_spconv(down[0], "backbone_3d.%s.0.0" % name, x, si + 1, ("down", si + 1), 27, down[1], True)
             self.steps.append(("index_subm", si + 1))
@@ -306,17 +329,18 @@ class Engine:
         kvol = int(np.prod(conv.kernel_size))
         lv_out = self._new_level(ops.conv_out_shape(lv_in["shape"], conv.kernel_size, conv.stride, conv.padding))
         lv_out["down"] = dict(src=3, ksize=conv.kernel_size, stride=conv.stride, pad=conv.padding,
-                              nbr=torch.full((cap, kvol), -1, dtype=i32, device=dev))
+                              nbr=torch.full((lv_out["cap"], kvol), -1, dtype=i32, device=dev))
         self.steps.append(("index_down", 4))
         x = self._compile_spconv(co[0], "backbone_3d.conv_out.0", x, 4, ("down", 4), kvol, co[1], True)
         self.encoded = (x, 4)
         self._alloc_index_ws()
         self._plan_static_sparse()
 
-    def _alloc_index_ws(self):
-        L = ops._lib.load()
-        need = max(L.aq3d_conv_outputs_workspace_bytes(self.cap, 27, self.levels[0]["table"].size), 256)
-        self.index_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
+    def _alloc_index_ws(self, n_points=0):
+        """One scratch buffer for every index builder of the plan (they are ordered on the plan's stream)."""
+        self._index_pts = int(n_points)
+        self.index_ws = ops.index_workspace(max(lv["cap"] for lv in self.levels), max(lv["index"].words for lv in self.levels),
+                                            self._index_pts, self.device)
 
     # ------------------------------------------------------------------ VoxelNeXt: sparse backbone, 2-D tail and head
     def _build_voxelnext(self, bb, head):
@@ -329,13 +353,11 @@ class Engine:
         x6, l6 = self.multi_scale["x_conv6"]
         assert x4["C"] == x5["C"] == x6["C"], "bev_out concatenates rows: equal channel counts"
         _, H, W = self.levels[l4]["shape"]
-        lv_m = self._new_level([1, H, W], kvol=1)
+        lv_m = self._new_level([1, H, W], kvol=1, bound=sum(self.levels[l]["cap"] for l in (l4, l5, l6)))
         mi = len(self.levels) - 1
         merged = self._tensor(mi, x4["C"], "backbone_3d.bev_out")
         L = ops._lib.load()
-        self.merge = dict(srcs=[(x4, l4, 1), (x5, l5, 2), (x6, l6, 4)], out=merged, level=mi,
-                          ws=torch.empty((max(L.aq3d_bev_merge_workspace_bytes(3, cap, lv_m["table"].size), 256),),
-                                         dtype=torch.uint8, device=dev))
+        self.merge = dict(srcs=[(x4, l4, 1), (x5, l5, 2), (x6, l6, 4)], out=merged, level=mi)
         self.steps.append(("bev_merge", None))
         self.steps.append(("absmax", merged))
         # conv_out: SparseConv2d 3x3 s1 p1 → dilated site set
@@ -347,7 +369,7 @@ class Engine:
         oi = len(self.levels) - 1
         lv_o["subm_ksize"] = k3
         lv_o["down"] = dict(src=mi, ksize=k3, stride=(1,) + tuple(conv.stride), pad=(0,) + tuple(conv.padding),
-                            nbr=torch.full((cap, int(np.prod(k3))), -1, dtype=i32, device=dev))
+                            nbr=torch.full((lv_o["cap"], int(np.prod(k3))), -1, dtype=i32, device=dev))
         self.steps.append(("index_down", oi))
         x = self._compile_spconv(co[0], "backbone_3d.conv_out.0", merged, oi, ("down", oi), int(np.prod(k3)), co[1], True)
         # shared_conv: SubMConv2d 3x3 on the same sites
@@ -356,7 +378,7 @@ class Engine:
         ks = (1,) + tuple(conv.kernel_size)
         lv_o["subm_ksize"] = ks
         if int(np.prod(ks)) != lv_o["nbr"].shape[1]:
-            lv_o["nbr"] = torch.full((cap, int(np.prod(ks))), -1, dtype=i32, device=dev)
+            lv_o["nbr"] = torch.full((lv_o["cap"], int(np.prod(ks))), -1, dtype=i32, device=dev)
         self.steps.append(("index_subm", oi))
         x = self._compile_spconv(sc[0], "backbone_3d.shared_conv.0", x, oi, oi, int(np.prod(ks)), sc[1], True)
         self.encoded = (x, oi)
@@ -370,7 +392,7 @@ class Engine:
                 self.head_nbr[k] = oi
                 continue
             self.head_nbr[k] = key
-            lv_o.setdefault("extra_nbr", {})[k] = torch.full((cap, k * k), -1, dtype=i32, device=dev)
+            lv_o.setdefault("extra_nbr", {})[k] = torch.full((lv_o["cap"], k * k), -1, dtype=i32, device=dev)
         self.steps.append(("index_head", oi))
         pp = head.model_cfg.POST_PROCESSING
         K = int(pp.MAX_OBJ_PER_SAMPLE)
@@ -694,7 +716,8 @@ class Engine:
                 absmax_out=self.arena.view(r["out"]["amax"])) for r in recs])
             G["w_mode"] = ops.W_I8 if r0["weight"].dtype == torch.int8 else ops.W_F32
         with _Timed(self, "spconv_c%d" % r0["cout"]):
-            ops.spconv_group(G["args"], ops.ACT_F32, G["w_mode"], self.cap, self.cap, r0["cin"], r0["cout"], r0["kvol"], r0["relu"])
+            ops.spconv_group(G["args"], ops.ACT_F32, G["w_mode"], lv["cap"], self.levels[r0["x"]["level"]]["cap"], r0["cin"], r0["cout"],
+                             r0["kvol"], r0["relu"])
 
     def _group_head_convs(self, first, B):
         """The SeparateHead branches are independent chains of small convs (center_head.py:12-46): reorder them by depth
@@ -784,44 +807,83 @@ class Engine:
                     ops.conv2d_f32_group(G["conv_args"][b])
 
     # ------------------------------------------------------------------ execution
-    def _voxelize(self, batch_dict, B):
+    def _voxel_cfg(self, stride, has_b):
+        return ops.make_voxel_cfg(self.pc_range, self.voxel_size, self.grid_size, self.num_point_features, stride, has_b,
+                                  self.max_points_per_voxel, self.max_voxels)
+
+    def _voxelize(self, batch_dict, B, exact_limit=False):
+        """Level 0 of the frame: active voxels, their rows and mean features (+ the level's gather tables).
+        Raw points (the usual case): hard voxelization on the device straight into the index level. Pre-voxelized batch_dict
+        (pcdet contract: voxels [M,P,C], voxel_num_points [M], voxel_coords [M,4]): MeanVFE + the level from the coordinates.
+        exact_limit: the frame has more than MAX_NUMBER_OF_VOXELS voxels — reproduce the reference's first-seen truncation with
+        the order-preserving voxelizer (aq3d_voxelize), then proceed as for pre-voxelized input."""
         lv0 = self.levels[0]
+        ix = lv0["index"]
         if "voxels" in batch_dict and "voxel_coords" in batch_dict and not getattr(self.det, "voxelize_on_device", False):
-            # pre-voxelized input (pcdet contract: voxels [M,P,C], voxel_num_points [M], voxel_coords [M,4] float)
             vox = batch_dict["voxels"].to(self.device, f32).contiguous()
             m = vox.shape[0]
             if m > self.cap:
                 raise ValueError("batch has %d voxels, engine capacity is %d" % (m, self.cap))
+            coords = batch_dict["voxel_coords"].to(self.device).to(i32).contiguous()
+            self._need_index_ws(m)
+            rows = ops.level_from_coords(coords, ix, workspace=self.index_ws)
             if m > 0:
-                self.vfe_feats[:m] = ops.mean_vfe(vox, batch_dict["voxel_num_points"].to(self.device))
-                lv0["coords"][:m] = batch_dict["voxel_coords"].to(self.device).to(i32)
-            lv0["count"].fill_(m)
+                ops.mean_vfe(vox, batch_dict["voxel_num_points"].to(self.device), rows=rows, out=self.vfe_feats)
+            self._level_tables(0)
             return
         pts = batch_dict["points"]
         assert pts.is_cuda, "points must be on the device (load_data_to_gpu)"
         stride = pts.shape[1]
         has_b = stride == self.num_point_features + 1
-        cfg = ops.make_voxel_cfg(self.pc_range, self.voxel_size, self.grid_size, self.num_point_features, stride, has_b,
-                                 self.max_points_per_voxel, self.max_voxels)
-        out = (lv0["coords"], self.vfe_feats, self.vfe_npts, lv0["count"])
+        cfg = self._voxel_cfg(stride, has_b)
+        if not exact_limit:
+            self._need_index_ws(pts.shape[0])
+            ops.level_from_points(pts, cfg, ix, feats_out=self.vfe_feats, npts_out=self.vfe_npts, workspace=self.index_ws)
+            self._level_tables(0)
+            return
+        # first-seen order + MAX_NUMBER_OF_VOXELS per sample, sample by sample (data_processor.py:45-61 runs per sample)
+        tmp = (torch.zeros((self.cap, 4), dtype=i32, device=self.device), torch.zeros((self.cap, self.num_point_features), dtype=f32, device=self.device),
+               torch.zeros((self.cap,), dtype=i32, device=self.device), torch.zeros((1,), dtype=i32, device=self.device))
         if has_b and B > 1:
-            # samples are contiguous row ranges (collate_batch concatenates in batch order); ranges are host data
             offs = batch_dict.get("points_batch_offsets", None)
             if offs is None:
-                bcol = pts[:, 0].to(torch.int64)
-                cnt = torch.bincount(bcol, minlength=B).cpu().tolist()          # one small D2H, batch > 1 only
+                cnt = torch.bincount(pts[:, 0].to(torch.int64), minlength=B).cpu().tolist()
                 offs = np.concatenate([[0], np.cumsum(cnt)]).tolist()
             for b in range(B):
-                seg = pts[offs[b]:offs[b + 1]]
-                need = ops._lib.load().aq3d_voxelize_workspace_bytes(max(seg.shape[0], 1))
-                if self._voxel_ws is None or self._voxel_ws.numel() < need:
-                    self._voxel_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
-                ops.voxelize(seg, cfg, self.cap, batch_index=b, append=b > 0, out=out, workspace=self._voxel_ws)
+                ops.voxelize(pts[offs[b]:offs[b + 1]], cfg, self.cap, batch_index=b, append=b > 0, out=tmp)
         else:
-            need = ops._lib.load().aq3d_voxelize_workspace_bytes(max(pts.shape[0], 1))
-            if self._voxel_ws is None or self._voxel_ws.numel() < need:
-                self._voxel_ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
-            ops.voxelize(pts, cfg, self.cap, batch_index=0, append=False, out=out, workspace=self._voxel_ws)
+            ops.voxelize(pts, cfg, self.cap, batch_index=0, append=False, out=tmp)
+        m = int(tmp[3].item())
+        self._need_index_ws(m)
+        rows = ops.level_from_coords(tmp[0][:m].contiguous(), ix, workspace=self.index_ws)
+        if m > 0:      # rows of the level <- the voxel means (x / 1 is exact)
+            ops.mean_vfe(tmp[1][:m].contiguous().view(m, 1, -1), torch.ones((m,), dtype=f32, device=self.device), rows=rows, out=self.vfe_feats)
+        self._level_tables(0)
+
+    def _need_index_ws(self, n_points):
+        if n_points > self._index_pts:
+            self._alloc_index_ws((int(n_points) + 16383) // 16384 * 16384)
+            self._graphs = {}
+
+    def _level_tables(self, li):
+        """Every gather table that hangs on level li (submanifold tables, the strided conv that produces the level, head kernels)
+        in one launch per four tables; the job arrays are built once."""
+        lv = self.levels[li]
+        if lv["jobs"] is None:
+            jobs = []
+            ix = lv["index"]
+            d = lv.get("down")
+            if d is not None:
+                jobs.append((self.levels[d["src"]]["index"], d["ksize"], d["stride"], d["pad"], d["nbr"]))
+            if ("index_subm", li) in [(k_, a_) for k_, a_ in self.steps if k_ == "index_subm"]:
+                ks = lv["subm_ksize"]
+                assert lv["nbr"].shape[1] == int(np.prod(ks))
+                jobs.append((ix, ks, (1, 1, 1), tuple(k // 2 for k in ks), lv["nbr"]))
+            for k, nbr in lv.get("extra_nbr", {}).items():
+                jobs.append((ix, (1, k, k), (1, 1, 1), (0, k // 2, k // 2), nbr))
+            lv["jobs"] = ops.nbr_jobs(jobs) if jobs else ()
+        if len(lv["jobs"]):
+            ops.level_neighbors(lv["index"], lv["jobs"])
 
     def start_timing(self, categories=None):
         self.timers, self.timer_filter = {}, (set(categories) if categories else None)
@@ -923,7 +985,7 @@ class Engine:
                 return
             L = ops._lib.load()
             with _Timed(self, "quantize_rows"):
-                ops.check(L.aq3d_quantize_rows(ops._p(x["buf"]), ops._p(amax), ops._p(in_count), self.cap, x["C"], q["bits"],
+                ops.check(L.aq3d_quantize_rows(ops._p(x["buf"]), ops._p(amax), ops._p(in_count), int(x["buf"].shape[0]), x["C"], q["bits"],
                                                int(q["per_tensor"]), None, ops._p(rec["fq"]), ops._p(rec["dq"]), ops._stream()),
                           "aq3d_quantize_rows")
             feats = rec["fq"]
@@ -1040,6 +1102,7 @@ class Engine:
         """Enqueue one batch on the current stream. Results sit in self.heads[*]['out_*'] and self.det_counts (slot self.slot);
         Detector.forward_async calls this on the plan's own stream."""
         B = self.begin(batch_dict)
+        self._slot_batch[self.slot] = batch_dict
         if self._graph_now:
             batch_dict = self._stage_points(batch_dict)
             self._static_batch = batch_dict
@@ -1083,10 +1146,10 @@ class Engine:
                 self._graphs = {}
         enqueue()
 
-    def _enqueue(self, batch_dict, B):
+    def _enqueue(self, batch_dict, B, exact_limit=False):
         self.arena.clear()
         with _Timed(self, "voxelize"):
-            self._voxelize(batch_dict, B)
+            self._voxelize(batch_dict, B, exact_limit)
         self._run_steps(self.steps, B)
 
     # ------------------------------------------------------------------ hipGraph replay
@@ -1119,6 +1182,7 @@ class Engine:
             buf[:] = far.to(self.device)
             self._pts_far = far.to(self.device)
             self._pts_buf, self._pts_n, self._graphs = buf, 0, {}
+            self._need_index_ws(cap_pts)            # allocate outside the capture that follows
         buf[:n].copy_(pts)
         if self._pts_n > n:
             buf[n:self._pts_n] = self._pts_far
@@ -1129,6 +1193,7 @@ class Engine:
         """Detection counts of this frame → pinned host memory, stream-ordered, plus an event: collect() waits for THIS frame
         only, so the caller may already have enqueued the next one (forward_async)."""
         self.host_counts[self.slot].copy_(self.det_counts[self.slot], non_blocking=True)
+        self.host_stats[self.slot].copy_(self._stats_pool, non_blocking=True)       # every level's site totals (overflow check)
         self._ev_done[self.slot].record()
 
     INDEX_KINDS = ("index_subm", "index_down", "index_head")
@@ -1167,28 +1232,22 @@ class Engine:
                     self._voxel_decode_nms()
 
     def _run_index(self, kind, arg):
-        if kind == "index_subm":
-            lv = self.levels[arg]
+        # "index_subm" / "index_head" only register tables at compile time: every table of a level is built with the level
+        if kind == "index_down":
             with _Timed(self, "rulebook"):
-                if "down" not in lv:   # level 0: table from the voxel coords; deeper levels get it from conv_outputs
-                    ops.hash_build(lv["coords"], lv["count"], lv["shape"], lv["table"])
-                ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], lv["subm_ksize"], lv["table"], out=lv["nbr"])
-        elif kind == "index_down":
-            with _Timed(self, "rulebook"):
-                self._index_down(arg)
-        elif kind == "index_head":
-            lv = self.levels[arg]
-            with _Timed(self, "rulebook"):
-                for k, nbr in lv.get("extra_nbr", {}).items():
-                    ops.subm_neighbors(lv["coords"], lv["count"], lv["shape"], (1, k, k), lv["table"], out=nbr)
+                lv_out = self.levels[arg]
+                d = lv_out["down"]
+                ops.level_downsample(self.levels[d["src"]]["index"], d["ksize"], d["stride"], d["pad"], lv_out["index"],
+                                     workspace=self.index_ws)
+                self._level_tables(arg)
 
     def _bev_merge(self):
         m = self.merge
         lv = self.levels[m["level"]]
-        srcs = [dict(coords=self.levels[l]["coords"], count=self.levels[l]["count"], feats=x["buf"], table=self.levels[l]["table"],
-                     shape=self.levels[l]["shape"], scale=sc) for x, l, sc in m["srcs"]]
-        ops.bev_merge(srcs, lv["shape"][1], lv["shape"][2], out=(lv["coords"], lv["count"], m["out"]["buf"], lv["table"]),
-                      workspace=m["ws"])
+        levels = [self.levels[l]["index"] for _, l, _ in m["srcs"]]
+        scales = [sc for _, _, sc in m["srcs"]]
+        ops.level_merge(levels, scales, lv["index"], workspace=self.index_ws)
+        ops.level_merge_sum(levels, [x["buf"] for x, _, _ in m["srcs"]], scales, lv["index"], feats_out=m["out"]["buf"])
 
     def _voxel_decode_nms(self):
         b = 0
@@ -1203,25 +1262,45 @@ class Engine:
         for args, _ in self._head_batches(b, make):
             ops.decode_nms_batch(args)
 
-    def _index_down(self, li):
-        lv_out = self.levels[li]
-        d = lv_out["down"]
-        lv_in = self.levels[d["src"]]
-        L = ops._lib.load()
-        kvol = int(np.prod(d["ksize"]))
-        t_in, t_out = lv_in["table"], lv_out["table"]
-        ops.check(L.aq3d_conv_outputs(ops._p(lv_in["coords"]), ops._p(lv_in["count"]), self.cap, ops.I3(*lv_in["shape"]),
-                                      ops.I3(*d["ksize"]), ops.I3(*d["stride"]), ops.I3(*d["pad"]), ops._p(t_in.keys),
-                                      ops._p(t_in.vals), t_in.size, ops._p(lv_out["coords"]), ops._p(lv_out["count"]),
-                                      self.cap, ops._p(d["nbr"]), ops._p(t_out.keys), ops._p(t_out.vals), t_out.size,
-                                      ops._p(self.index_ws), self.index_ws.numel(), ops._stream()), "aq3d_conv_outputs")
-
     # ------------------------------------------------------------------ results
     def counts(self, B, slot=None):
         """Per-head detection counts of the frame in `slot` (default: the latest) — waits for that frame only."""
         slot = self.slot if slot is None else slot
         self._ev_done[slot].synchronize()
+        self._check_levels(slot, B)
         return self.host_counts[slot, :B].numpy().copy()
+
+    def _check_levels(self, slot, B):
+        """A level that outgrew its buffers invalidates the frame: raise (the kernels clamp, they never write out of bounds).
+        More voxels than MAX_NUMBER_OF_VOXELS in a sample: the reference keeps the first-seen ones — redo the frame that way."""
+        st = self.host_stats[slot].numpy()
+        bd = self._slot_batch[slot]
+        if int(st[0, 2]) > self.max_voxels and bd is not None and "points" in bd and "voxels" not in bd:
+            self._slot_batch[slot] = None
+            return self._rerun_first_seen(slot, bd, B)
+        for li, lv in enumerate(self.levels):
+            total = int(st[li, 1])
+            if total > lv["cap"]:
+                what = "voxel_capacity" if li == 0 else "level_capacity[%d] / level_capacity_factor" % li
+                raise ValueError("index level %d: %d active sites > capacity %d rows — the frame was NOT computed; raise "
+                                 "detector.%s (spconv sizes its outputs dynamically, spconv_backbone.py:230-231)"
+                                 % (li, total, lv["cap"], what))
+
+    def _rerun_first_seen(self, slot, batch_dict, B):
+        """Rare path: a sample holds more than MAX_NUMBER_OF_VOXELS voxels. Everything in flight on the device finishes, then the
+        frame runs again, eagerly, into its own result slot with the order-preserving voxelizer."""
+        torch.cuda.synchronize(self.device)
+        stream = getattr(self, "stream", None) or torch.cuda.current_stream(self.device)
+        keep = self.slot
+        self.slot = slot
+        try:
+            with torch.cuda.stream(stream):
+                self._enqueue(batch_dict, B, exact_limit=True)
+                self._publish()
+            self._ev_done[slot].synchronize()
+        finally:
+            self.slot = keep
+        self._check_levels(slot, B)
 
     def collect(self, B, slot=None):
         """One device→host read (the detection counts), then slice the padded outputs into pred_dicts."""

@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class Aq3dError(RuntimeError):
@@ -57,6 +57,16 @@ class SpconvProblem(Structure):
                 ("nbr", c_void_p), ("count_out", c_void_p), ("feats_out", c_void_p), ("absmax_out", c_void_p)]
 
 
+class Level(Structure):
+    _fields_ = [("shape", c_int32 * 3), ("batch", c_int32), ("cap", c_int32), ("reserved", c_int32), ("bits", c_void_p),
+                ("base", c_void_p), ("row_of_rank", c_void_p), ("coords", c_void_p), ("count", c_void_p), ("total", c_void_p)]
+
+
+class NbrJob(Structure):
+    _fields_ = [("level_in", POINTER(Level)), ("ksize", c_int32 * 3), ("stride", c_int32 * 3), ("pad", c_int32 * 3),
+                ("nbr", c_void_p)]
+
+
 class SqPrepProblem(Structure):
     _fields_ = [("pieces", c_void_p), ("weight", c_void_p), ("w_colmax", c_void_p), ("geom", POINTER(Conv2dGeom)),
                 ("alpha", c_float), ("static_amax_x", c_float), ("static_amax_w", c_void_p), ("amax_x_acc", c_void_p),
@@ -72,12 +82,15 @@ SIGNATURES = {
     "aq3d_abi_version": (c_int32, []),
     "aq3d_voxelize_workspace_bytes": (c_size_t, [c_int32]),
     "aq3d_voxelize": (c_int32, [P, c_int32, POINTER(VoxelCfg), c_int32, c_int32, P, P, P, P, c_int32, P, c_size_t, P]),
-    "aq3d_mean_vfe": (c_int32, [P, P, c_int32, c_int32, c_int32, P, P]),
-    "aq3d_hash_build": (c_int32, [P, P, c_int32, I3, P, P, c_int32, P]),
-    "aq3d_subm_neighbors": (c_int32, [P, P, c_int32, I3, I3, P, P, c_int32, P, P]),
-    "aq3d_conv_outputs_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
-    "aq3d_conv_outputs": (c_int32, [P, P, c_int32, I3, I3, I3, I3, P, P, c_int32, P, P, c_int32, P, P, P, c_int32,
-                                    P, c_size_t, P]),
+    "aq3d_mean_vfe": (c_int32, [P, P, c_int32, c_int32, c_int32, P, P, P]),
+    "aq3d_level_words": (c_int64, [I3, c_int32]),
+    "aq3d_index_workspace_bytes": (c_size_t, [c_int32, c_int64, c_int32]),
+    "aq3d_level_from_points": (c_int32, [P, c_int32, POINTER(VoxelCfg), c_int32, POINTER(Level), P, P, P, c_size_t, P]),
+    "aq3d_level_from_coords": (c_int32, [P, c_int32, POINTER(Level), P, P, c_size_t, P]),
+    "aq3d_level_downsample": (c_int32, [POINTER(Level), I3, I3, I3, POINTER(Level), P, c_size_t, P]),
+    "aq3d_level_neighbors": (c_int32, [POINTER(Level), POINTER(NbrJob), c_int32, P]),
+    "aq3d_level_merge": (c_int32, [P, P, c_int32, POINTER(Level), P, c_size_t, P]),
+    "aq3d_level_merge_sum": (c_int32, [P, P, P, c_int32, c_int32, POINTER(Level), P, P]),
     "aq3d_absmax_cols": (c_int32, [P, P, c_int32, c_int32, P, P]),
     "aq3d_quantize_rows": (c_int32, [P, P, P, c_int32, c_int32, c_int32, c_int32, P, P, P, P]),
     "aq3d_spconv": (c_int32, [P, c_int32, P, P, c_int32, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32,
@@ -106,9 +119,6 @@ SIGNATURES = {
     "aq3d_nms_rotated": (c_int32, [P, c_int32, P, c_int32, c_float, c_int32, P, P, P, c_size_t, P]),
     "aq3d_gather_dets": (c_int32, [P, c_int32, P, P, P, P, P, c_int32, P, P, P, P]),
     "aq3d_decode_nms_batch": (c_int32, [POINTER(HeadProblem), c_int32, P]),
-    "aq3d_bev_merge_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
-    "aq3d_bev_merge": (c_int32, [P, P, P, P, P, P, P, P, c_int32, c_int32, c_int32, c_int32, c_int32, P, P, P, c_int32, P, P,
-                                 c_int32, P, c_size_t, P]),
     "aq3d_voxel_decode": (c_int32, [P, P, P, P, P, P, P, P, c_int32, POINTER(DecodeCfg), P, P, P, P, P, c_size_t, P]),
     "aq3d_boxes_iou3d": (c_int32, [P, c_int32, c_int32, P, c_int32, c_int32, P, P]),
     "aq3d_recall_counts": (c_int32, [P, c_int32, c_int32, P, c_int32, P, P]),

@@ -35,17 +35,6 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _pow2_at_least(n):
-    t = 1024
-    while t < n:
-        t <<= 1
-    return t
-
-
-def table_size_for(cap):
-    return _pow2_at_least(2 * max(int(cap), 1))
-
-
 # ------------------------------------------------------------------ voxelization
 def make_voxel_cfg(point_cloud_range, voxel_size, grid_size, num_features, point_stride, batch_col,
                    max_points_per_voxel, max_voxels):
@@ -83,38 +72,127 @@ def voxelize(points, cfg, cap, batch_index=0, append=False, out=None, workspace=
     return coords, feats, npts, count
 
 
-def mean_vfe(voxels, num_points):
+def mean_vfe(voxels, num_points, rows=None, out=None):
+    """voxels f32 [m, P, C] → mean features; rows i32 [m] (optional) sends voxel v to row rows[v] of `out` (-1: dropped)."""
     L = _lib.load()
     m, P, C = voxels.shape
-    out = torch.empty((m, C), dtype=f32, device=voxels.device)
-    check(L.aq3d_mean_vfe(_p(voxels), _p(num_points.to(f32).contiguous()), m, P, C, _p(out), _stream()), "aq3d_mean_vfe")
+    if out is None:
+        out = torch.empty((m, C), dtype=f32, device=voxels.device)
+    check(L.aq3d_mean_vfe(_p(voxels), _p(num_points.to(f32).contiguous()), m, P, C, _p(rows), _p(out), _stream()), "aq3d_mean_vfe")
     return out
 
 
-# ------------------------------------------------------------------ sparse index generation
-class HashTable:
-    def __init__(self, cap, device):
-        self.size = table_size_for(cap)
-        self.keys = torch.empty((self.size,), dtype=torch.int64, device=device)
-        self.vals = torch.empty((self.size,), dtype=i32, device=device)
+# ------------------------------------------------------------------ sparse index levels
+class IndexLevel:
+    """Device arrays of one index level (include/aq3d.h: aq3d_level) + the ctypes struct that names them."""
+
+    def __init__(self, shape, batch, cap, device, stats=None):
+        L = _lib.load()
+        self.shape, self.batch, self.cap = [int(v) for v in shape], int(batch), int(cap)
+        self.words = int(L.aq3d_level_words(I3(*self.shape), self.batch))
+        self.bits = torch.zeros((self.words,), dtype=torch.int64, device=device)
+        self.base = torch.zeros((self.words,), dtype=i32, device=device)
+        self.row_of_rank = torch.zeros((self.cap,), dtype=i32, device=device)
+        self.coords = torch.zeros((self.cap, 4), dtype=i32, device=device)
+        # count | total[2] share one 4-int row so that a plan can read every level's totals back with one copy
+        self.stats = stats if stats is not None else torch.zeros((4,), dtype=i32, device=device)
+        self.count, self.total = self.stats[0:1], self.stats[1:3]
+        c = _lib.Level()
+        for j in range(3):
+            c.shape[j] = self.shape[j]
+        c.batch, c.cap, c.reserved = self.batch, self.cap, 0
+        c.bits, c.base, c.row_of_rank = self.bits.data_ptr(), self.base.data_ptr(), self.row_of_rank.data_ptr()
+        c.coords, c.count, c.total = self.coords.data_ptr(), self.count.data_ptr(), self.total.data_ptr()
+        self.c = c
+
+    def live(self):
+        """(rows, total sites, largest per-sample total) — one device→host read."""
+        v = self.stats[:3].cpu().tolist()
+        return int(v[0]), int(v[1]), int(v[2])
 
 
-def hash_build(coords, count, shape, table=None):
+def index_workspace(max_cap, max_words, max_points, device):
+    """Scratch of the index builders (zero-initialised: its first 256 bytes hold self-resetting arrival counters)."""
+    need = _lib.load().aq3d_index_workspace_bytes(int(max_cap), int(max_words), int(max_points))
+    return torch.zeros((need,), dtype=torch.uint8, device=device)
+
+
+def _ws_for(level, points, workspace):
+    need = _lib.load().aq3d_index_workspace_bytes(level.cap, level.words, int(points))
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.zeros((need,), dtype=torch.uint8, device=level.bits.device)
+    return workspace
+
+
+def level_from_points(points, cfg, level, feats_out=None, npts_out=None, batch_index=0, workspace=None):
+    """Hard voxelization + mean VFE straight into `level` (rows in the level's order). → (feats f32 [cap, C], npts i32 [cap])."""
     L = _lib.load()
-    cap = coords.shape[0]
-    table = table or HashTable(cap, coords.device)
-    check(L.aq3d_hash_build(_p(coords), _p(count), cap, I3(*shape), _p(table.keys), _p(table.vals), table.size,
-                            _stream()), "aq3d_hash_build")
-    return table
+    n = int(points.shape[0])
+    if feats_out is None:
+        feats_out = torch.zeros((level.cap, cfg.num_features), dtype=f32, device=points.device)
+    if npts_out is None:
+        npts_out = torch.zeros((level.cap,), dtype=i32, device=points.device)
+    workspace = _ws_for(level, n, workspace)
+    check(L.aq3d_level_from_points(_p(points), n, ctypes.byref(cfg), int(batch_index), ctypes.byref(level.c), _p(feats_out),
+                                   _p(npts_out), _p(workspace), workspace.numel(), _stream()), "aq3d_level_from_points")
+    return feats_out, npts_out
 
 
-def subm_neighbors(coords, count, shape, ksize, table, out=None):
+def level_from_coords(coords, level, workspace=None, rows_out=None):
+    """coords i32 [n, 4] rows (b, z, y, x) → builds `level`, returns row_of_input i32 [n]."""
     L = _lib.load()
-    cap = coords.shape[0]
+    n = int(coords.shape[0])
+    if rows_out is None:
+        rows_out = torch.empty((max(n, 1),), dtype=i32, device=coords.device)
+    workspace = _ws_for(level, n, workspace)
+    check(L.aq3d_level_from_coords(_p(coords) if n else None, n, ctypes.byref(level.c), _p(rows_out), _p(workspace),
+                                   workspace.numel(), _stream()), "aq3d_level_from_coords")
+    return rows_out[:n]
+
+
+def level_downsample(level_in, ksize, stride, pad, level_out, workspace=None):
+    L = _lib.load()
+    workspace = _ws_for(level_out, 0, workspace)
+    check(L.aq3d_level_downsample(ctypes.byref(level_in.c), I3(*ksize), I3(*stride), I3(*pad), ctypes.byref(level_out.c),
+                                  _p(workspace), workspace.numel(), _stream()), "aq3d_level_downsample")
+    return level_out
+
+
+def nbr_jobs(jobs):
+    """ctypes array of aq3d_nbr_job from (level_in, ksize, stride, pad, nbr tensor i32 [cap_out, kvol]) tuples."""
+    arr = (_lib.NbrJob * len(jobs))()
+    for q, (lin, ks, st, pd, nbr) in zip(arr, jobs):
+        assert nbr.dtype == i32 and nbr.is_contiguous() and nbr.shape[1] == ks[0] * ks[1] * ks[2]
+        q.level_in = ctypes.pointer(lin.c)
+        for j in range(3):
+            q.ksize[j], q.stride[j], q.pad[j] = int(ks[j]), int(st[j]), int(pd[j])
+        q.nbr = nbr.data_ptr()
+    return arr
+
+
+def level_neighbors(level_out, jobs):
+    """Gather tables of `level_out` (<= 4 per launch). jobs: nbr_jobs(...) array or a list of tuples."""
+    if isinstance(jobs, (list, tuple)):
+        jobs = nbr_jobs(jobs)
+    L = _lib.load()
+    i = 0
+    while i < len(jobs):          # one launch: <= 4 tables and <= 64 table entries per row
+        n, width = 0, 0
+        while i + n < len(jobs) and n < 4:
+            kv = jobs[i + n].ksize[0] * jobs[i + n].ksize[1] * jobs[i + n].ksize[2]
+            if n > 0 and width + kv > 64:
+                break
+            n, width = n + 1, width + kv
+        sub = ctypes.cast(ctypes.byref(jobs, i * ctypes.sizeof(_lib.NbrJob)), ctypes.POINTER(_lib.NbrJob))
+        check(L.aq3d_level_neighbors(ctypes.byref(level_out.c), sub, n, _stream()), "aq3d_level_neighbors")
+        i += n
+
+
+def subm_neighbors(level, ksize=(3, 3, 3), out=None):
+    """Gather table of a submanifold conv on `level`: i32 [cap, kvol]."""
     kvol = ksize[0] * ksize[1] * ksize[2]
-    nbr = out if out is not None else torch.empty((cap, kvol), dtype=i32, device=coords.device)
-    check(L.aq3d_subm_neighbors(_p(coords), _p(count), cap, I3(*shape), I3(*ksize), _p(table.keys), _p(table.vals),
-                                table.size, _p(nbr), _stream()), "aq3d_subm_neighbors")
+    nbr = out if out is not None else torch.empty((level.cap, kvol), dtype=i32, device=level.bits.device)
+    level_neighbors(level, [(level, ksize, (1, 1, 1), tuple(k // 2 for k in ksize), nbr)])
     return nbr
 
 
@@ -122,24 +200,30 @@ def conv_out_shape(shape, ksize, stride, pad):
     return [(shape[i] + 2 * pad[i] - ksize[i]) // stride[i] + 1 for i in range(3)]
 
 
-def conv_outputs(coords_in, count_in, shape_in, ksize, stride, pad, in_table, cap_out, workspace=None):
-    """→ (coords_out i32 [cap_out,4], count_out i32 [1], nbr i32 [cap_out,kvol], out_table)."""
+def level_merge(levels, scales, level_out, workspace=None):
+    """VoxelNeXt bev_out index: union of <= 3 levels projected onto (y, x) → 2-D `level_out`."""
     L = _lib.load()
-    dev = coords_in.device
-    cap_in = coords_in.shape[0]
-    kvol = ksize[0] * ksize[1] * ksize[2]
-    out_table = HashTable(cap_out, dev)
-    coords_out = torch.empty((cap_out, 4), dtype=i32, device=dev)
-    count_out = torch.zeros((1,), dtype=i32, device=dev)
-    nbr = torch.empty((cap_out, kvol), dtype=i32, device=dev)
-    need = L.aq3d_conv_outputs_workspace_bytes(cap_in, kvol, out_table.size)
-    if workspace is None or workspace.numel() < need:
-        workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
-    check(L.aq3d_conv_outputs(_p(coords_in), _p(count_in), cap_in, I3(*shape_in), I3(*ksize), I3(*stride), I3(*pad),
-                              _p(in_table.keys), _p(in_table.vals), in_table.size, _p(coords_out), _p(count_out),
-                              cap_out, _p(nbr), _p(out_table.keys), _p(out_table.vals), out_table.size,
-                              _p(workspace), workspace.numel(), _stream()), "aq3d_conv_outputs")
-    return coords_out, count_out, nbr, out_table
+    n = len(levels)
+    ptrs = (ctypes.c_void_p * n)(*[ctypes.addressof(l.c) for l in levels])
+    sc = (ctypes.c_int32 * n)(*[int(v) for v in scales])
+    workspace = _ws_for(level_out, 0, workspace)
+    check(L.aq3d_level_merge(ptrs, sc, n, ctypes.byref(level_out.c), _p(workspace), workspace.numel(), _stream()), "aq3d_level_merge")
+    return level_out
+
+
+def level_merge_sum(levels, feats, scales, level_out, feats_out=None):
+    L = _lib.load()
+    n = len(levels)
+    C = feats[0].shape[1]
+    ptrs = (ctypes.c_void_p * n)(*[ctypes.addressof(l.c) for l in levels])
+    fp = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
+    sc = (ctypes.c_int32 * n)(*[int(v) for v in scales])
+    for l, f in zip(levels, feats):
+        assert f.shape == (l.cap, C) and f.dtype == f32 and f.is_contiguous()
+    if feats_out is None:
+        feats_out = torch.zeros((level_out.cap, C), dtype=f32, device=feats[0].device)
+    check(L.aq3d_level_merge_sum(ptrs, fp, sc, n, C, ctypes.byref(level_out.c), _p(feats_out), _stream()), "aq3d_level_merge_sum")
+    return feats_out
 
 
 # ------------------------------------------------------------------ sparse conv + quantizer
@@ -456,38 +540,6 @@ def voxel_decode(hm, center, center_z, dim, rot, vel, coords, count, cfg, worksp
                               ctypes.byref(cfg), _p(boxes), _p(scores), _p(labels), _p(cnt), _p(workspace), workspace.numel(),
                               _stream()), "aq3d_voxel_decode")
     return boxes, scores, labels, cnt
-
-
-def bev_merge(srcs, H, W, out=None, workspace=None):
-    """VoxelNeXt bev_out. srcs: up to 3 dicts(coords [cap,4] i32, count i32[1], feats f32 [cap,C], table HashTable (3-D, built),
-    shape (z,y,x), scale). → (coords_out [cap,4] rows (b,0,y,x), count_out, feats_out [cap,C], table_out)."""
-    L = _lib.load()
-    n = len(srcs)
-    cap, C = srcs[0]["feats"].shape
-    dev = srcs[0]["feats"].device
-    for s_ in srcs:
-        assert s_["feats"].shape == (cap, C) and s_["coords"].shape == (cap, 4)
-    if out is None:
-        out = (torch.zeros((cap, 4), dtype=i32, device=dev), torch.zeros((1,), dtype=i32, device=dev),
-               torch.zeros((cap, C), dtype=f32, device=dev), HashTable(cap, dev))
-    coords_o, count_o, feats_o, table_o = out
-    need = L.aq3d_bev_merge_workspace_bytes(n, cap, table_o.size)
-    if workspace is None or workspace.numel() < need:
-        workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
-    PA = ctypes.c_void_p * n
-    arr = lambda key, f=lambda v: v: PA(*[f(s_[key]).data_ptr() for s_ in srcs])
-    coords = arr("coords")
-    counts = arr("count")
-    feats = arr("feats")
-    keys = PA(*[s_["table"].keys.data_ptr() for s_ in srcs])
-    vals = PA(*[s_["table"].vals.data_ptr() for s_ in srcs])
-    tsz = (ctypes.c_int32 * n)(*[s_["table"].size for s_ in srcs])
-    shapes = (ctypes.c_int32 * (3 * n))(*[int(v) for s_ in srcs for v in s_["shape"]])
-    scales = (ctypes.c_int32 * n)(*[int(s_["scale"]) for s_ in srcs])
-    check(L.aq3d_bev_merge(coords, counts, feats, keys, vals, tsz, shapes, scales, n, cap, C, int(H), int(W), _p(coords_o),
-                           _p(count_o), _p(feats_o), coords_o.shape[0], _p(table_o.keys), _p(table_o.vals), table_o.size,
-                           _p(workspace), workspace.numel(), _stream()), "aq3d_bev_merge")
-    return coords_o, count_o, feats_o, table_o
 
 
 def nms_rotated(boxes, count, thresh, post_max, workspace=None, out=None):

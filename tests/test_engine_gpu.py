@@ -174,3 +174,64 @@ def test_stale_pending_frame_raises_and_weight_load_rebuilds_the_plan(dev, monke
     with torch.no_grad():
         got = _np(model(_batch(ds, 0, dev))[0][0])
     assert len(got[1]) < len(ref[1])
+
+
+def test_capacity_overflow_raises(dev):
+    """A strided level that outgrows its buffers (spconv would simply allocate more, spconv_backbone.py:230-231) must not be
+    computed on a truncated site set: counts() / forward() raise and name the level; with room the same frame runs."""
+    ds, model = _model(quantized=False)
+    with torch.no_grad():
+        ref = _np(model(_batch(ds, 0, dev))[0][0])
+    eng = model.engine()
+    live = [int(lv["count"].item()) for lv in eng.levels]
+    assert all(n > 0 for n in live)
+    for use_graph in (False, True):
+        model.level_capacity = {1: max(256, live[1] // 2 // 256 * 256)}
+        model.invalidate_engine()
+        model.engine().use_graph = use_graph
+        with torch.no_grad():
+            for _ in range(2):
+                with pytest.raises(ValueError, match="index level 1: %d active sites" % live[1]):
+                    model(_batch(ds, 0, dev))
+            p = model.forward_async(_batch(ds, 0, dev))
+            with pytest.raises(ValueError, match="level_capacity"):
+                p.counts()
+    model.level_capacity = None
+    model.voxel_capacity = live[0] - 10           # level 0 itself
+    model.invalidate_engine()
+    with torch.no_grad(), pytest.raises(ValueError, match="index level 0"):
+        model(_batch(ds, 0, dev))
+    model.voxel_capacity = None
+    model.invalidate_engine()
+    with torch.no_grad():
+        assert _same(ref, _np(model(_batch(ds, 0, dev))[0][0]))
+
+
+def test_max_voxels_keeps_the_first_seen_voxels(dev):
+    """MAX_NUMBER_OF_VOXELS below the frame's voxel count: the reference's voxel generator keeps the first-seen ones
+    (data_processor.py:45-61). The index builder does not order by first sight, so the engine redoes such a frame with the
+    order-preserving voxelizer; the result equals the frame voxelized on the host and passed in pre-voxelized."""
+    from amdq3d.datasets import load_data_to_gpu
+    from oracle import voxel as OVX
+    cfg = small_cfg("waymo")
+    vox = {c.NAME: c for c in cfg.DATA_CONFIG.DATA_PROCESSOR}["transform_points_to_voxels"]
+    vox.MAX_NUMBER_OF_VOXELS = {"train": 1500, "test": 1500}
+    ds, model = build_model(cfg, n_points=9000, n_voxels=2500, n_frames=2)
+    model.cuda()
+    b = ds.collate_batch([ds[0]])
+    pts = np.asarray(b["points"])[:, 1:]
+    voxels, coords, num = OVX.hard_voxelize(pts, cfg.DATA_CONFIG.POINT_CLOUD_RANGE, [float(v) for v in vox.VOXEL_SIZE],
+                                            vox.MAX_POINTS_PER_VOXEL, 1500)
+    assert len(coords) == 1500
+    load_data_to_gpu(b, dev)
+    with torch.no_grad():
+        got = _np(model(dict(b))[0][0])
+        eng = model.engine()
+        assert int(eng.levels[0]["count"].item()) == 1500
+        got_async = _np(model.forward_async(dict(b)).result()[0][0])
+        pre = dict(b)
+        pre.update(voxels=torch.from_numpy(voxels).to(dev), voxel_num_points=torch.from_numpy(num).to(dev),
+                   voxel_coords=torch.from_numpy(np.concatenate([np.zeros((len(coords), 1), np.float32), coords.astype(np.float32)], 1)).to(dev))
+        model.voxelize_on_device = False
+        ref = _np(model(pre)[0][0])
+    assert len(ref[1]) > 0 and _same(ref, got) and _same(ref, got_async)

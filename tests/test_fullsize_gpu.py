@@ -81,7 +81,7 @@ def test_w150k_fp32_end_to_end(dev, w150k):
     assert eng.grid_size == [1504, 1504, 40] and eng.levels[0]["shape"] == [41, 1504, 1504]
     assert int(eng.levels[0]["count"].item()) == 30000
     maps = teacher.row_maps(eng, _cp_index_sets(trace))                 # asserts every level's site set bit-exact
-    # voxel features (hard voxelization + mean) bit-exact, in first-seen order on both sides
+    # voxel features (hard voxelization + mean) bit-exact, row by row through the site map
     np.testing.assert_array_equal(eng.vfe_feats[:30000].cpu().numpy(), trace["vfe"][0][maps[0]])
     same_order = np.array_equal(eng.levels[0]["coords"][:30000].cpu().numpy(), trace["vfe"][1])
     print("voxel rows in the oracle's first-seen order:", same_order)
@@ -160,11 +160,14 @@ def test_subm_layer_30k(dev, w150k, C):
     nbr_ref = OS.subm_neighbors(idx, shape)
     xq, _ = OS.qconv_act(x, 8, cw=True)
     ref = np.maximum(OS.gather_conv(xq, wq, nbr_ref, bias), 0)
-    coords = torch.from_numpy(idx.astype(np.int32)).to(dev)
     count = torch.tensor([m], dtype=torch.int32, device=dev)
-    table = ops.hash_build(coords, count, shape)
-    nbr = ops.subm_neighbors(coords, count, shape, (3, 3, 3), table)
-    np.testing.assert_array_equal(nbr.cpu().numpy(), nbr_ref)          # gather table bit-exact (same row order on both sides)
+    lv = ops.IndexLevel(shape, 1, m, dev)
+    rows = ops.level_from_coords(torch.from_numpy(idx.astype(np.int32)).to(dev), lv).cpu().numpy()      # oracle row i -> device row
+    assert lv.live()[:2] == (m, m) and sorted(rows.tolist()) == list(range(m))
+    nbr = ops.subm_neighbors(lv)
+    np.testing.assert_array_equal(nbr.cpu().numpy()[rows], np.where(nbr_ref >= 0, rows[np.maximum(nbr_ref, 0)], -1))   # gather table bit-exact
+    inv = np.argsort(rows)                                              # device row r holds oracle row inv[r]
+    x, ref = x[inv], ref[inv]
     xd = torch.from_numpy(x).to(dev)
     amax = ops.absmax_cols(xd, count)
     # production path: int8-coded gather, per-channel scale folded into the per-frame weight copy

@@ -348,3 +348,61 @@ def test_frame_readers_waymo_npy_and_nuscenes_sweeps(tmp_path):
     (root / "bad.bin").write_bytes(b"\0" * 12)
     with pytest.raises(ValueError):
         read_nuscenes_sweep(root / "bad.bin")
+
+
+def _strided_level_sizes(idx, shape, geoms):
+    """Active-set sizes of a chain of strided sparse convs (the site-set half of oracle.sparse.conv_outputs, without the tables)."""
+    from oracle import sparse as OS
+    sizes = [len(idx)]
+    for ks, st, pd in geoms:
+        oshape = OS.out_shape(shape, ks, st, pd)
+        keys = []
+        for kz in range(ks[0]):
+            for ky in range(ks[1]):
+                for kx in range(ks[2]):
+                    num = idx[:, 1:].astype(np.int64) + np.asarray(pd) - np.asarray([kz, ky, kx])
+                    ok = np.all((num >= 0) & (num % np.asarray(st) == 0), axis=1)
+                    o = num // np.asarray(st)
+                    ok &= np.all(o < np.asarray(oshape), axis=1)
+                    keys.append(OS._key(np.concatenate([idx[ok, :1].astype(np.int64), o[ok]], 1), oshape))
+        keys = np.unique(np.concatenate(keys))
+        o = np.empty((len(keys), 4), np.int64)
+        rest = keys
+        for j, d in zip((3, 2, 1), (oshape[2], oshape[1], oshape[0])):
+            o[:, j], rest = rest % d, rest // d
+        o[:, 0] = rest
+        idx, shape = o, oshape
+        sizes.append(len(idx))
+    return sizes
+
+
+def test_bench_frames_fit_the_bench_capacities():
+    """VERDICT r2 / ADVICE r2: rank 1's seed-15 frame holds 66 132 rows at the first strided level — more than the 65 536 rows
+    round 2's bench gave every level, and the overflow was clamped silently. Every frame the eight ranks of `bench.py --gpus 8`
+    run (seeds 4 .. 67) must fit the row capacities bench.py configures; the device raises if one does not (tests/test_engine_gpu.py)."""
+    import bench
+    from amdq3d.config import AttrDict, cfg_from_yaml_file
+    from amdq3d.synthetic import make_frame
+    from oracle import voxel as OV
+    cfg = cfg_from_yaml_file("cfgs/waymo_models/centerpoint.yaml", AttrDict())
+    pr = cfg.DATA_CONFIG.POINT_CLOUD_RANGE
+    vs = [0.1, 0.1, 0.15]
+    grid = OV.grid_size_of(pr, vs)
+    shape = [int(grid[2]) + 1, int(grid[1]), int(grid[0])]
+    geoms = [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)), ((3, 1, 1), (2, 1, 1), (0, 0, 0))]
+    cap0, factor = 40960, 2.5                       # bench.py::build (AQ3D_VOXEL_CAP / AQ3D_LEVEL_FACTOR defaults)
+    src = open(os.path.join(os.path.dirname(bench.__file__), "bench.py")).read()
+    assert '"AQ3D_VOXEL_CAP", "%d"' % cap0 in src and '"AQ3D_LEVEL_FACTOR", "%s"' % factor in src
+    worst = [0] * 5
+    for rank in range(8):
+        for i in range(bench.N_FRAMES):
+            seed = bench.rank_seed0(rank) + i
+            pts = make_frame(seed, bench.N_POINTS, bench.N_VOXELS, pr, vs, grid)
+            _, c, _ = OV.voxelize_mean(pts, pr, vs, 5, 150000)
+            sizes = _strided_level_sizes(c.astype(np.int64), shape, geoms)
+            if seed == 15:
+                assert sizes[1] == 66132              # the frame the round-2 bench would have truncated
+            worst = [max(a, b) for a, b in zip(worst, sizes)]
+    caps = [cap0] + [int(np.ceil(factor * cap0))] * 4
+    assert all(w <= c for w, c in zip(worst, caps)), (worst, caps)
+    assert worst[1] > 65536

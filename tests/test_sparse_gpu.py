@@ -83,38 +83,123 @@ def _sparse_input(dev, m_pts=6000, seed=3, batch=2):
     return idx, shape
 
 
-def test_subm_neighbors_exact(dev):
+def _level_of(dev, idx, shape, batch, extra_cap=100):
+    """Index level built from the given sites → (level, rows): oracle row i lives in device row rows[i]."""
+    from amdq3d import ops
+    lv = ops.IndexLevel(shape, batch, len(idx) + extra_cap, dev)
+    rows = ops.level_from_coords(torch.from_numpy(np.ascontiguousarray(idx)).to(dev), lv).cpu().numpy()
+    n, total, _ = lv.live()
+    assert n == total == len(idx)
+    assert sorted(rows.tolist()) == list(range(len(idx)))                 # a permutation of the live rows
+    np.testing.assert_array_equal(lv.coords[:n].cpu().numpy()[rows], idx)  # every row carries its site
+    return lv, rows
+
+
+def _renumber(nbr_ref, rows_in):
+    """The oracle's gather table in the device's input-row numbering."""
+    return np.where(nbr_ref >= 0, rows_in[np.maximum(nbr_ref, 0)], -1)
+
+
+@pytest.mark.parametrize("ksize", [(3, 3, 3), (1, 3, 3), (1, 1, 1)])
+def test_subm_neighbors_exact(dev, ksize):
     from amdq3d import ops
     idx, shape = _sparse_input(dev)
-    cap = len(idx) + 100
-    coords = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
-    coords[:len(idx)] = torch.from_numpy(idx).to(dev)
-    count = torch.tensor([len(idx)], dtype=torch.int32, device=dev)
-    table = ops.hash_build(coords, count, shape)
-    nbr = ops.subm_neighbors(coords, count, shape, (3, 3, 3), table)[:len(idx)].cpu().numpy()
-    np.testing.assert_array_equal(nbr, OS.subm_neighbors(idx, shape, (3, 3, 3)))
+    lv, rows = _level_of(dev, idx, shape, 2)
+    nbr = ops.subm_neighbors(lv, ksize)[:len(idx)].cpu().numpy()
+    np.testing.assert_array_equal(nbr[rows], _renumber(OS.subm_neighbors(idx, shape, ksize), rows))
+
+
+def test_level_row_classes(dev):
+    """Rows are grouped by neighbourhood class, heaviest class first (csrc/sites.hip): the class weight never rises along the rows,
+    and rows of one class keep the bitmap's raster order (8x8 patches of a z slice, then the cells inside a patch)."""
+    from amdq3d import ops
+    idx, shape = _sparse_input(dev, m_pts=9000, seed=11)
+    lv, rows = _level_of(dev, idx, shape, 2)
+    m = len(idx)
+    nb = OS.subm_neighbors(idx, shape).reshape(m, 3, 3, 3) >= 0
+    z, y, x = nb.any(axis=(2, 3)), nb.any(axis=(1, 3)), nb.any(axis=(1, 2))
+    key = (z * (1 << np.arange(3))).sum(1) + 8 * y[:, 0] + 16 * y[:, 2] + 32 * x[:, 0] + 64 * x[:, 2]
+    wgt = z.sum(1) * (1 + y[:, [0, 2]].sum(1)) * (1 + x[:, [0, 2]].sum(1))
+    order = np.argsort(rows)                   # oracle rows in device row order
+    assert np.all(np.diff(wgt[order]) <= 0)
+    i64 = idx.astype(np.int64)
+    PY, PX = (shape[1] + 7) // 8, (shape[2] + 7) // 8
+    patch = ((i64[:, 0] * shape[0] + i64[:, 1]) * PY + (i64[:, 2] >> 3)) * PX + (i64[:, 3] >> 3)
+    k_sorted, raster = key[order], (patch * 64 + (i64[:, 2] & 7) * 8 + (i64[:, 3] & 7))[order]
+    same = k_sorted[1:] == k_sorted[:-1]
+    assert np.all(np.diff(raster)[same] > 0)
+    # one class = one run of rows
+    assert len(np.unique(key)) == 1 + int((~same).sum())
 
 
 @pytest.mark.parametrize("ksize,stride,pad", [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (0, 1, 1)),
-                                              ((3, 1, 1), (2, 1, 1), (0, 0, 0))])
-def test_conv_outputs_exact(dev, ksize, stride, pad):
+                                              ((3, 1, 1), (2, 1, 1), (0, 0, 0)), ((1, 3, 3), (1, 1, 1), (0, 1, 1)),
+                                              ((3, 3, 3), (1, 2, 2), (1, 1, 0))])
+def test_level_downsample_exact(dev, ksize, stride, pad):
     from amdq3d import ops
     idx, shape = _sparse_input(dev, seed=5)
-    cap = len(idx) + 17
-    coords = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
-    coords[:len(idx)] = torch.from_numpy(idx).to(dev)
-    count = torch.tensor([len(idx)], dtype=torch.int32, device=dev)
-    table = ops.hash_build(coords, count, shape)
+    shape = [41, 157, 163]                        # not multiples of 8: edge patches
+    lv_in, rows_in = _level_of(dev, idx, shape, 2, extra_cap=17)
     o_ref, nbr_ref, oshape = OS.conv_outputs(idx, shape, ksize, stride, pad)
-    co, cnt, nbr, _ = ops.conv_outputs(coords, count, shape, ksize, stride, pad, table, cap_out=len(o_ref) + 33)
-    m = int(cnt.item())
-    assert m == len(o_ref)
-    co, nbr = co[:m].cpu().numpy(), nbr[:m].cpu().numpy()
+    lv_out = ops.IndexLevel(oshape, 2, len(o_ref) + 33, dev)
+    ops.level_downsample(lv_in, ksize, stride, pad, lv_out)
+    m, total, _ = lv_out.live()
+    assert m == total == len(o_ref)
+    kvol = int(np.prod(ksize))
+    nbr = torch.full((lv_out.cap, kvol), -7, dtype=torch.int32, device=dev)
+    ops.level_neighbors(lv_out, [(lv_in, ksize, stride, pad, nbr)])
+    co, nbr = lv_out.coords[:m].cpu().numpy(), nbr[:m].cpu().numpy()
     key = OS._key(co, oshape)
     assert len(np.unique(key)) == m
     order = np.argsort(key)
-    np.testing.assert_array_equal(co[order], o_ref)     # same active set
-    np.testing.assert_array_equal(nbr[order], nbr_ref)  # same gather table, row for row
+    np.testing.assert_array_equal(co[order], o_ref)                            # same active set
+    np.testing.assert_array_equal(nbr[order], _renumber(nbr_ref, rows_in))     # same gather table, row for row
+
+
+def test_level_overflow_is_reported(dev):
+    """A level that outgrows its buffers keeps count <= cap, reports the true total, and never writes beyond the capacity."""
+    from amdq3d import ops
+    idx, shape = _sparse_input(dev, seed=6)
+    lv_in, _ = _level_of(dev, idx, shape, 2)
+    o_ref, _, oshape = OS.conv_outputs(idx, shape, (3, 3, 3), (2, 2, 2), (1, 1, 1))
+    cap = len(o_ref) // 2
+    lv_out = ops.IndexLevel(oshape, 2, cap, dev)
+    guard = torch.full((cap + 64, 27), -7, dtype=torch.int32, device=dev)
+    ops.level_downsample(lv_in, (3, 3, 3), (2, 2, 2), (1, 1, 1), lv_out)
+    ops.level_neighbors(lv_out, [(lv_in, (3, 3, 3), (2, 2, 2), (1, 1, 1), guard[:cap])])
+    n, total, _ = lv_out.live()
+    assert n == cap and total == len(o_ref)
+    assert int((guard[cap:] != -7).sum().item()) == 0
+    small = ops.IndexLevel(shape, 2, 100, dev)
+    ops.level_from_coords(torch.from_numpy(idx).to(dev), small)
+    assert small.live()[:2] == (100, len(idx))
+
+
+def test_level_from_points_matches_the_voxelizer(dev):
+    """aq3d_level_from_points = the voxel generator's cells and means, rows in index order; total[1] counts per sample."""
+    from amdq3d import ops
+    grid = OV.grid_size_of(RANGE, VSIZE)
+    a, b = _cloud(20000, 7), _cloud(9000, 8)
+    fa, ca, na = OV.voxelize_mean(a, RANGE, VSIZE, 5, 10 ** 9, batch_index=0)
+    fb, cb, nb = OV.voxelize_mean(b, RANGE, VSIZE, 5, 10 ** 9, batch_index=1)
+    pts = np.concatenate([np.concatenate([np.zeros((len(a), 1), np.float32), a], 1), np.concatenate([np.ones((len(b), 1), np.float32), b], 1)])
+    cfg = ops.make_voxel_cfg(RANGE, VSIZE, grid, 5, 6, True, 5, 150000)
+    lv = ops.IndexLevel([grid[2] + 1, grid[1], grid[0]], 2, len(ca) + len(cb) + 50, dev)
+    feats, npts = ops.level_from_points(torch.from_numpy(pts).to(dev), cfg, lv)
+    n, total, per_sample = lv.live()
+    assert n == total == len(ca) + len(cb) and per_sample == max(len(ca), len(cb))
+    co = lv.coords[:n].cpu().numpy()
+    ref_c, ref_f, ref_n = np.concatenate([ca, cb]), np.concatenate([fa, fb]), np.concatenate([na, nb])
+    shape = [grid[2] + 1, grid[1], grid[0]]
+    order, ro = np.argsort(OS._key(co, shape)), np.argsort(OS._key(ref_c, shape))
+    np.testing.assert_array_equal(co[order], ref_c[ro])
+    np.testing.assert_array_equal(feats[:n].cpu().numpy()[order].view(np.uint32), ref_f[ro].view(np.uint32))   # bit-exact means
+    np.testing.assert_array_equal(npts[:n].cpu().numpy()[order], ref_n[ro])
+    # an empty cloud / everything out of range
+    ops.level_from_points(torch.full((10, 6), 100.0, device=dev), cfg, lv)
+    assert lv.live() == (0, 0, 0)
+    ops.level_from_points(torch.zeros((0, 6), device=dev), cfg, lv)
+    assert lv.live() == (0, 0, 0)
 
 
 @pytest.mark.parametrize("cin,cout", [(5, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (64, 128), (128, 128)])

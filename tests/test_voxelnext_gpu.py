@@ -1,4 +1,4 @@
-"""GPU parity of the VoxelNeXt (fully sparse) path — BASELINE configs[4], SURVEY.md §8a row 20: aq3d_bev_merge and
+"""GPU parity of the VoxelNeXt (fully sparse) path — BASELINE configs[4], SURVEY.md §8a row 20: aq3d_level_merge and
 aq3d_voxel_decode against their oracle restatements, then VoxelNeXt.forward against oracle.voxelnext.run."""
 import numpy as np
 import pytest
@@ -18,13 +18,12 @@ def _level(rng, n, shape, C, dev, cap):
     keys = rng.choice(D * H * W, size=n, replace=False)
     idx = np.stack([np.zeros(n, np.int64), keys // (H * W), (keys // W) % H, keys % W], 1).astype(np.int32)
     feats = rng.standard_normal((n, C)).astype(np.float32)
-    coords = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
-    coords[:n] = torch.from_numpy(idx).to(dev)
+    lv = ops.IndexLevel(list(shape), 1, cap, dev)
+    rows = ops.level_from_coords(torch.from_numpy(idx).to(dev), lv).cpu().numpy()
     fb = torch.zeros((cap, C), dtype=torch.float32, device=dev)
-    fb[:n] = torch.from_numpy(feats).to(dev)
-    count = torch.tensor([n], dtype=torch.int32, device=dev)
-    table = ops.hash_build(coords, count, shape)
-    return idx, feats, dict(coords=coords, count=count, feats=fb, table=table, shape=list(shape))
+    if n:
+        fb[torch.from_numpy(rows).to(dev).long()] = torch.from_numpy(feats).to(dev)
+    return idx, feats, dict(level=lv, feats=fb)
 
 
 @pytest.mark.parametrize("sizes", [(700, 300, 90), (1, 0, 0), (0, 0, 5)])
@@ -39,16 +38,19 @@ def test_bev_merge_vs_oracle(dev, sizes):
         d["scale"] = sc
         srcs.append(d)
         host.append((feats, idx, sc))
-    co, cnt, fo, table = ops.bev_merge(srcs, 48, 40)
+    out = ops.IndexLevel([1, 48, 40], 1, cap, dev)
+    levels, scales = [d["level"] for d in srcs], [d["scale"] for d in srcs]
+    ops.level_merge(levels, scales, out)
+    fo = ops.level_merge_sum(levels, [d["feats"] for d in srcs], scales, out)
     f_ref, i_ref = OV.bev_out(host)
-    m = int(cnt.item())
+    m = out.live()[0]
     assert m == len(i_ref)
-    got = co[:m].cpu().numpy()
+    got = out.coords[:m].cpu().numpy()
     order = np.argsort(OS._key(got, [1, 48, 40]))
     np.testing.assert_array_equal(got[order], i_ref)                       # same site set, rows (b, 0, y, x)
     np.testing.assert_allclose(fo[:m].cpu().numpy()[order], f_ref, rtol=0, atol=2e-6 * max(1.0, np.abs(f_ref).max()))
-    # the emitted hash table addresses the merged rows: a 1x1 submanifold table is the identity
-    nbr = ops.subm_neighbors(co, cnt, [1, 48, 40], (1, 1, 1), table)
+    # the merged level addresses its own rows: a 1x1 submanifold table is the identity
+    nbr = ops.subm_neighbors(out, (1, 1, 1))
     np.testing.assert_array_equal(nbr[:m, 0].cpu().numpy(), np.arange(m))
 
 
@@ -117,8 +119,7 @@ def test_voxelnext_fp32_vs_oracle(dev):
         x, idx, shape = trace["levels"][name]
         m, co, order = _sorted_rows(eng, li, shape)
         assert m == len(idx), name
-        if li > 0:      # level 0 keeps the voxelizer's row order in both
-            np.testing.assert_array_equal(co[order], idx)
+        np.testing.assert_array_equal(co[order], idx[np.argsort(OS._key(idx, shape))])     # same site set at every level
     x, idx, shape = trace["encoded"]
     m, co, order = _sorted_rows(eng, eng.encoded[1], shape)
     assert m == len(idx)
@@ -160,8 +161,10 @@ def test_voxelnext_int8_vs_oracle(dev, cw):
     assert m == len(idx)
     np.testing.assert_array_equal(co[order], idx)
     # first residual stage: before rounding flips can cascade
-    x1 = trace["levels"]["x_conv1"][0]
-    g1 = eng.multi_scale["x_conv1"][0]["buf"][:len(x1)].cpu().numpy()
+    x1, idx1, shape1 = trace["levels"]["x_conv1"]
+    m1, co1, order1 = _sorted_rows(eng, 0, shape1)
+    x1 = x1[np.argsort(OS._key(idx1, shape1))]                  # oracle rows (voxelizer order) in key order, like the device rows
+    g1 = eng.multi_scale["x_conv1"][0]["buf"][:m1].cpu().numpy()[order1]
     tol = 1e-4 * max(1.0, float(np.abs(x1).max()))
     assert (np.abs(g1 - x1) <= tol).mean() >= 0.999
     fo = eng.encoded[0]["buf"][:m].cpu().numpy()[order]
