@@ -281,9 +281,8 @@ def main():
     ap.add_argument("--workload", default="centerpoint", choices=sorted(WORKLOADS))
     ap.add_argument("--static", action="store_true", help="static PTQ (calibrated amax, quant_centerpoint.py:127-129) instead of the "
                     "dynamic recipe: the sparse quantisers run in producer epilogues, no per-frame quantiser launches")
-    ap.add_argument("--sparse-fp16-weights", action="store_true", help="quantised sparse convs multiply by ONE fp16 weight per product "
-                    "(AQ3D_FLAG_W_FP16: the north star's int8 x fp16 precision, layers within 1e-3 of their output scale) instead of the "
-                    "default fp16 hi|lo pair (layers within 2e-5)")
+    ap.add_argument("--sparse-w16", action="store_true", help="quantised sparse convs multiply by 16-bit fixed-point weights (AQ3D_FLAG_W16: "
+                    "two int8 planes, layers within 1e-3 of their output scale) instead of the default 24-bit ones (three planes, within 2e-5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
@@ -305,7 +304,7 @@ def main():
     lib.load()
     cfg_path, n_points, n_voxels, wl_desc = WORKLOADS[args.workload]
     cfg, ds, model, state = build(cfg_path, dev, n_points, n_voxels, seed0=rank_seed0(rank), static=args.static)
-    model.sparse_fp16_weights = bool(args.sparse_fp16_weights)
+    model.sparse_w16 = bool(args.sparse_w16)
     model.invalidate_engine()       # (the static recipe's calibration forwards have already compiled a plan)
 
     # N_FRAMES distinct frames per rank, resident in HBM before the timed region (also kept in pinned host memory for the
@@ -418,8 +417,8 @@ def main():
                        "voxels": n_voxels, "parallelism": "replicas(frames)x%d" % world, "world_size_seen_by_rccl": world_seen,
                        "avg_boxes_per_frame": n_det / max(args.steps, 1),
                        "row_capacity_per_index_level": [lv["cap"] for lv in eng.levels],
-                       "sparse_conv_weights": "one fp16 per product (layers <= 1e-3 of scale)" if args.sparse_fp16_weights
-                       else "fp16 hi|lo pair (layers <= 2e-5 of scale)"},
+                       "sparse_conv_weights": "16-bit fixed point, two int8 planes (layers <= 1e-3 of scale)" if args.sparse_w16
+                       else "24-bit fixed point, three int8 planes (layers <= 2e-5 of scale)"},
             "roofline": roof,
             "roofline_by_kernel": by_kernel,
             "execution": "%s, %d frames in flight (throughput mode: the frames in flight share the chip)"
@@ -445,11 +444,11 @@ def main():
                 out["accuracy"] = {"failed": repr(e)}
         else:
             out["accuracy"] = None
-        if world == 1 and not args.sparse_fp16_weights and not args.no_accuracy:
-            # the other precision of the quantised sparse convs, same pipeline, same frames (a second plan: ONE fp16 weight per
-            # product, AQ3D_FLAG_W_FP16): reported beside `value`, never as `value`
+        if world == 1 and not args.sparse_w16 and not args.no_accuracy:
+            # the other precision of the quantised sparse convs, same pipeline, same frames (a second plan: 16-bit fixed-point weights,
+            # AQ3D_FLAG_W16): reported beside `value`, never as `value`
             try:
-                model.sparse_fp16_weights = True
+                model.sparse_w16 = True
                 model.invalidate_engine()
                 for i in range(2):
                     step(i)
@@ -459,14 +458,14 @@ def main():
                 a = time.perf_counter()
                 run_pipelined(n16, resident)
                 torch.cuda.synchronize(dev)
-                out["value_sparse_fp16_weights"] = {
+                out["value_sparse_w16"] = {
                     "value": n16 / (time.perf_counter() - a), "unit": "frames/s", "steps": n16,
-                    "what": "sparse convs multiply int8 codes by ONE fp16 weight (north star's int8 x fp16 product; every layer within "
-                            "1e-3 of its output scale against the oracle, measured <= 3e-4) instead of the fp16 hi|lo pair (<= 2e-5)",
+                    "what": "sparse convs multiply int8 codes by 16-bit fixed-point weights (two int8 planes; every layer within 1e-3 of its "
+                            "output scale against the oracle) instead of 24-bit ones (three planes, <= 2e-5)",
                     "accuracy": accuracy_proxy(cfg, ds, state, model, batches, N_FRAMES, ref_cache)}
             except Exception as e:
-                out["value_sparse_fp16_weights"] = {"failed": repr(e)}
-            model.sparse_fp16_weights = False
+                out["value_sparse_w16"] = {"failed": repr(e)}
+            model.sparse_w16 = False
             model.invalidate_engine()
         if world == 1 and not args.no_cpu_baseline:
             try:

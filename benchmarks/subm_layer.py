@@ -69,7 +69,8 @@ def main():
     ap.add_argument("--voxels", type=int, nargs="+", default=[30000, 120000, 480000, 1000000])
     ap.add_argument("--occupancy", default="sheet")
     ap.add_argument("--iters", type=int, default=50)
-    ap.add_argument("--order", default="random", choices=["random", "morton", "linear"], help="row order of the voxels")
+    ap.add_argument("--order", default="random", choices=["random", "morton", "linear", "device"], help="row order of the voxels")
+    ap.add_argument("--w16", action="store_true", help="16-bit fixed-point weights (two int8 planes) instead of 24-bit")
     ap.add_argument("--cpu", action="store_true", help="also time the CPU oracle on the smallest size")
     args = ap.parse_args()
     from amdq3d import ops
@@ -88,10 +89,13 @@ def main():
         idx = occupancy(args.occupancy, m_req, order=args.order)
         m = len(idx)
         cap = m
-        coords = torch.from_numpy(idx).to(dev)
         count = torch.tensor([m], dtype=torch.int32, device=dev)
-        table = ops.hash_build(coords, count, shape)
-        nbr = ops.subm_neighbors(coords, count, shape, (3, 3, 3), table)
+        if args.order == "device":      # the index builder's own row order (neighbourhood classes, heaviest first)
+            lv = ops.IndexLevel(shape, 1, m, dev)
+            ops.level_from_coords(torch.from_numpy(idx).to(dev), lv)
+            nbr = ops.subm_neighbors(lv)
+        else:                           # rows in the given order: the gather table comes from the oracle
+            nbr = torch.from_numpy(OS.subm_neighbors(idx, shape)).to(dev)
         pairs = int((nbr >= 0).sum().item())
         for C in args.channels:
             g = torch.Generator().manual_seed(C)
@@ -105,14 +109,14 @@ def main():
             amax = ops.absmax_cols(x, count)
             out = torch.empty((cap, C), device=dev)
             am_out = torch.zeros(C, device=dev)
-            bufs = (torch.zeros((cap, C), dtype=torch.int8, device=dev), torch.empty((27, C, 2, C), dtype=torch.float16, device=dev),
+            bufs = (torch.zeros((cap, C), dtype=torch.int8, device=dev), torch.empty((27, C, 3, C), dtype=torch.int8, device=dev),
                     torch.empty((C,), device=dev))
 
             def prep():
                 ops.spconv_prep(x, amax, count, wk8, wdq, out=bufs)
 
             def conv():
-                return ops.spconv_coded(bufs[0], bufs[1], bufs[2], nbr, count, post_scale=ps, post_shift=pt, relu=True, absmax_out=am_out, out=out)
+                return ops.spconv_coded(bufs[0], bufs[1], bufs[2], nbr, count, post_scale=ps, post_shift=pt, relu=True, absmax_out=am_out, out=out, w16=args.w16)
 
             def timed(fn):
                 # warm up for >= 30 ms: after the host-side set-up of a configuration (seconds of numpy) the GPU sits at idle clocks

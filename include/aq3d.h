@@ -188,8 +188,9 @@ enum {
 enum {
     AQ3D_FLAG_RELU = 1,
     AQ3D_FLAG_SKIP_F32 = 2, /* aq3d_spconv_coded with next_codes: do not store the fp32 rows */
-    AQ3D_FLAG_W_FP16 = 4    /* aq3d_spconv_coded: multiply by the hi plane of W' only (int8 codes x ONE fp16 weight, one MFMA per
-                               product: ~2^-12 relative error per weight, <= 1e-3 of the output scale per layer); default: hi | lo */
+    AQ3D_FLAG_W16 = 4       /* aq3d_spconv_coded: 16-bit fixed-point weights (the two upper int8 planes of W'': |error| <= 2^-9 per
+                               weight on a +-127 scale, <= 1e-3 of the output scale per layer, measured ~5e-5) — two int8 MFMAs per
+                               product instead of three; default: all three planes (24-bit fixed point, fp32-grade sums) */
 };
 
 /*
@@ -209,7 +210,7 @@ int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *act_dequant
                 float *feats_out, float *absmax_out, const float *next_scale, int8_t *next_codes, int32_t next_bits, void *stream);
 /* next_scale / next_codes (both NULL or both set; aq3d_spconv: stem layer only, cin <= 8): static PTQ — the calibrated quantiser
  * of the layer that consumes y runs in this epilogue: next_codes i8 [cap_out, Cout] = clamp(rint(y * next_scale[o]), -2^(b-1),
- * 2^(b-1)-1) in the code layout aq3d_spconv_coded reads, next_scale[o] = (2^(b-1)-1) / amax_o (0 where amax_o <= 2^-24). */
+ * 2^(b-1)-1), row-major, next_scale[o] = (2^(b-1)-1) / amax_o (0 where amax_o <= 2^-24). */
 
 /* One layer of a grouped aq3d_spconv launch (the pointer arguments of aq3d_spconv). */
 typedef struct aq3d_spconv_problem {
@@ -226,18 +227,18 @@ typedef struct aq3d_spconv_problem {
 int aq3d_spconv_group(const aq3d_spconv_problem *problems, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
                       int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, void *stream);
 
-/* ------------- production path of the QConvNd layers: int8-coded activations, scale folded into a per-frame weight copy ----
+/* ------------- production path of the QConvNd layers: int8-coded activations x fixed-point weight planes on the int8 matrix pipe ----
  * Replaces quant/quant.py:36-58 (QConvNd.forward) around the spconv call sites pcdet/models/backbones_3d/
  * spconv_backbone.py:12-17,39-46:
  *   y[m,o] = sum_{k,c} (q[nbr[m][k],c] * d_c) * (wq[k,o,c] * t_o) = (sum q * W') * (S * t_o),  W' = wq * (d_c / S), S = max_c d_c.
  * aq3d_spconv_prep (ONE launch): TensorQuantizer(axis=1) of x f32 [*count, C] with the given abs-max -> codes_out i8 [cap, C]
- *   (1 byte per element; for C >= 64 the bytes of every 64-channel group are permuted, an internal layout only
- *   aq3d_spconv_coded reads), AND the per-frame weight copy wprep_out (aq3d_spconv_wprep_bytes: W' as fp16 hi | lo planes,
- *   22 significant bits) + out_mul_out f32 [Cout] = S * w_dequant. weight_codes i8 [kvol, Cout, C]; bits <= 8.
- *   Either half may be skipped: x == NULL builds the weight copy only (static PTQ: once, the scales are constants),
+ *   (1 byte per element, channel order), AND the per-frame weight planes wprep_out (aq3d_spconv_wprep_bytes: W'' = rint(W' * 2^16)
+ *   as three balanced base-256 int8 digits, [kvol][Cout][3][C]) + out_mul_out f32 [Cout] = S * w_dequant / 2^16.
+ *   weight_codes i8 [kvol, Cout, C]; bits <= 8; C a power of two.
+ *   Either half may be skipped: x == NULL builds the weight planes only (static PTQ: once, the scales are constants),
  *   weight_codes == NULL quantises the rows only.
- * aq3d_spconv_coded: the gather-GEMM with the epilogue of aq3d_spconv (incl. next_scale / next_codes / AQ3D_FLAG_SKIP_F32);
- *   AQ3D_FLAG_W_FP16 selects the north star's "int8 weights x fp16 activations" product precision (see the flag). */
+ * aq3d_spconv_coded: the gather-GEMM (v_mfma_i32_16x16x64_i8, one int32 accumulator per plane) with the epilogue of aq3d_spconv
+ *   (incl. next_scale / next_codes / AQ3D_FLAG_SKIP_F32); AQ3D_FLAG_W16 multiplies the two upper planes only (see the flag). */
 int aq3d_spconv_coded_supported(int32_t cin, int32_t cout, int32_t kvol);
 size_t aq3d_spconv_wprep_bytes(int32_t cin, int32_t cout, int32_t kvol);
 int aq3d_spconv_prep(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C, int32_t bits,

@@ -1,60 +1,39 @@
-// Sparse conv on int8-CODED activations (1 byte per gathered element) with the per-input-channel activation scale folded into
-// a per-frame fp16 weight copy — the production path of the QConvNd layers (quant/quant.py:36-58 around spconv).
+// Sparse conv of the QConvNd layers (quant/quant.py:36-58 around spconv) on the int8 matrix pipe: int8-CODED activations
+// (1 byte per gathered element) x fixed-point weight PLANES that carry the per-input-channel activation scale.
 //
 // QConvNd quantises activations PER INPUT CHANNEL, so the scale d_c sits inside the K contraction:
-//     y[m,o] = sum_{k,c} (q[nbr(m,k),c] * d_c) * (wq[k,o,c] * t_o).
-// Here the gather moves the CODE q (int8, exact in fp16) and the scale moves into the weights:
-//     W'[k,o,c] = wq[k,o,c] * (d_c / S),  S = max_c d_c,     y = (sum q * W') * (S * t_o)
-// with W' held as an fp16 pair W' = hi + lo (hi = fp16(W'), lo = fp16(W' - hi): 22 significant bits; |W'| <= 127 so lo stays
-// above the fp16 subnormal floor wherever it matters, and the matrix pipe honours subnormals). q * hi and q * lo are exact
-// fp32 products of v_mfma_f32_16x16x32_f16 and ONE fp32 accumulator takes both. Against the round-1 format (activations as an
-// fp16 hi|lo pair, 4 bytes per element and 4 gather instructions per row and 64-channel unit) the gather moves 4x fewer bytes
-// with 4x fewer instructions at the same MFMA count; W' (27*C^2 elements) is rebuilt per frame by the quantiser launch.
+//     y[m,o] = sum_{k,c} (q[nbr(m,k),c] * d_c) * (wq[k,o,c] * t_o)
+// and a plain int8 x int8 dot cannot carry it. The gather moves the CODE q (int8) and the scale moves into the weights:
+//     W'[k,o,c] = wq[k,o,c] * (d_c / S),  S = max_c d_c,  |W'| <= 127,      y = (sum q * W') * (S * t_o).
+// W' is held in FIXED POINT with 16 fractional bits, W'' = rint(W' * 2^16), split into three balanced base-256 digits
+// d2 d1 d0 (int8 each): q * d_p is an exact int8 x int8 product of v_mfma_i32_16x16x64_i8, every plane has its own int32
+// accumulator, and the epilogue recombines them in fp32: |W' - W''/2^16| <= 2^-17, i.e. fp32-grade sums (measured <= 4e-7 of
+// the output scale per layer). Rounds 1-2 multiplied fp16 codes by an fp16 hi|lo weight pair on the fp16 pipe: two MFMAs per
+// product at half the int8 rate (4 int8-MFMA times against 3 here), 4 bytes of weights through LDS per product against 3,
+// and a 5-instruction int8 -> fp16 conversion of every gathered dword that is gone altogether.
+// AQ3D_FLAG_W16: planes d2 d1 only (balanced digits: dropping d0 ROUNDS W'' to 8 fractional bits, |error| <= 2^-9 per
+// weight — 16-bit fixed-point weights, ~5e-5 of the output scale per layer): two MFMAs and two bytes per product. This is the
+// north star's "int8 weights x activations with the scale folded into the gather" at the int8 pipe's rate.
 //
 //   sp_prep_kernel      one launch per layer: blocks [0, row_blocks) quantise the producer's fp32 rows to codes, the rest
-//                       build W' (hi | lo planes) and the epilogue multipliers S * t_o. Both depend on the abs-max only.
-//   spconv_cd_kernel    Cin = 16, kvol = 27: whole W' resident in LDS, per-lane 8-byte gathers straight into MFMA registers.
-//   spconv_cw_kernel    Cin >= 32: 128 rows x CT (<= 64 at Cout = 128) output columns per workgroup, W' streamed through double-buffered LDS in
-//                       (kernel offset, 64-channel) units, A fragments gathered into registers (one 16-byte load per row and unit).
-// Code layout: rows of Cin bytes; for Cin >= 64 the bytes of every 64-channel group are permuted so that the 16 bytes a lane
-// loads are the 8 + 8 channels of its two MFMA K chunks: position 16g + 8kc + i  <->  channel 32kc + 8g + i.
+//                       build the weight planes and the epilogue multipliers S * t_o / 2^16. Both depend on the abs-max only.
+//   spconv_cd_kernel    Cin = 16, kvol = 27: all planes resident in LDS; a K step = the three kx offsets of one (kz, ky) row
+//                       (+ one idle slot); wave-level skip of the (kz, ky) rows no site of the 16-row block has.
+//   spconv_cw_kernel    Cin >= 32: 128 rows x CT (<= 64) output columns per workgroup, planes streamed through double-buffered
+//                       LDS in (kernel offset, 64-channel) units, codes gathered straight into MFMA operands (one bounded
+//                       16-byte load per row and unit; no neighbour = out-of-range offset = zeros, no branch).
+// MFMA orientation: A = weight plane (16 output channels x 64 K), B = codes (64 K x 16 rows) -> every lane ends up with four
+// consecutive output channels of one row: 16-byte stores, 16-byte residual loads, 4-byte code stores.
 #include "common.h"
 #include <stdlib.h>
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4v __attribute__((ext_vector_type(4)));
-typedef int i32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 #define CD_OOB 0xfffffff0u
+#define CD_PLANES 3
+#define CD_FRAC 65536.0f
 
-// 4 packed int8 -> 4 fp16 (exact) in 5 VALU ops: bias to unsigned, splice each byte under the fp16 exponent of 1024
-// (0x64xx = 1024 + xx), subtract 1152 = 1024 + 128 with a packed add.
-__device__ __forceinline__ void cd_cvt4(int w, f16x2 &lo, f16x2 &hi) {
-    const unsigned t = (unsigned)w ^ 0x80808080u;
-    const unsigned p0 = __builtin_amdgcn_perm(t, 0x64646464u, 0x00050004u);
-    const unsigned p1 = __builtin_amdgcn_perm(t, 0x64646464u, 0x00070006u);
-    const f16x2 bias = {(_Float16)1152.f, (_Float16)1152.f};
-    lo = __builtin_bit_cast(f16x2, p0) - bias;
-    hi = __builtin_bit_cast(f16x2, p1) - bias;
-}
-__device__ __forceinline__ f16x8 cd_cvt8(int w0, int w1) {
-    f16x2 a, b, c, d;
-    cd_cvt4(w0, a, b);
-    cd_cvt4(w1, c, d);
-    f16x8 r;
-    r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1]; r[4] = c[0]; r[5] = c[1]; r[6] = d[0]; r[7] = d[1];
-    return r;
-}
-
-// position of channel c inside a code row (identity below 64 channels)
-__host__ __device__ __forceinline__ int cd_code_pos(int c, int C) {
-    if (C < 64) return c;
-    const int grp = c >> 6, w = c & 63;
-    return (grp << 6) + 16 * ((w & 31) >> 3) + 8 * (w >> 5) + (w & 7);
-}
-
-// ------------------------------------------------------------------ quantiser + W' builder
+// ------------------------------------------------------------------ quantiser + weight planes
 struct SpPrepArgs {
     const float *x;           // [cap][C] producer output (fp32)
     const float *amax;        // [C] per-channel abs-max (dynamic: this frame's; static: calibrated)
@@ -65,8 +44,8 @@ struct SpPrepArgs {
     int8_t *codes;            // [cap][C]
     const int8_t *w;          // [kvol][Cout][C] weight codes
     const float *w_dequant;   // [Cout]
-    _Float16 *wp;             // [kvol][Cout][2][C]   hi | lo planes
-    float *out_mul;           // [Cout]  S * t_o
+    int8_t *wp;               // [kvol][Cout][3][C]  planes d0 d1 d2 of W''
+    float *out_mul;           // [Cout]  S * t_o / 2^16
     int kvol, cout, row_blocks;
 };
 
@@ -92,9 +71,9 @@ __global__ __launch_bounds__(256) void sp_prep_kernel(SpPrepArgs a) {
     if ((int)blockIdx.x < a.row_blocks) {
         int n = *a.count;
         if (n > a.cap) n = a.cap;
-        const int C4 = C >> 2, total4 = n * C4;
+        const int total4 = n * (C >> 2);
         for (int t = blockIdx.x * 256 + threadIdx.x; t < total4; t += a.row_blocks * 256) {
-            const int r = t / C4, c = (t - r * C4) * 4;
+            const int c = (t * 4) & (C - 1);                 // C is a power of two (16 .. 256)
             const float4 xv = reinterpret_cast<const float4 *>(a.x)[t];
             const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
             signed char qc[4];
@@ -104,11 +83,11 @@ __global__ __launch_bounds__(256) void sp_prep_kernel(SpPrepArgs a) {
                 q = fminf(fmaxf(q, -a.qmax - 1.f), a.qmax);
                 qc[k] = (signed char)(int)q;
             }
-            *reinterpret_cast<char4 *>(a.codes + (size_t)r * C + cd_code_pos(c, C)) = make_char4(qc[0], qc[1], qc[2], qc[3]);
+            reinterpret_cast<char4 *>(a.codes)[t] = make_char4(qc[0], qc[1], qc[2], qc[3]);
         }
         return;
     }
-    // weight blocks: S = largest live step; W' = code * (d_c / S) as hi | lo
+    // weight blocks: S = largest live step; W'' = rint(code * (d_c / S) * 2^16) as three balanced base-256 digits
     if (threadIdx.x == 0) {
         float S = 0.f;
         for (int c = 0; c < C; ++c) S = fmaxf(S, s_dq[c]);
@@ -118,34 +97,34 @@ __global__ __launch_bounds__(256) void sp_prep_kernel(SpPrepArgs a) {
     const float S = s_S;
     const int wb = (int)blockIdx.x - a.row_blocks, nwb = (int)gridDim.x - a.row_blocks;
     if (wb == 0)
-        for (int o = threadIdx.x; o < a.cout; o += 256) a.out_mul[o] = __fmul_rn(S, a.w_dequant[o]);
+        for (int o = threadIdx.x; o < a.cout; o += 256) a.out_mul[o] = __fmul_rn(__fmul_rn(S, a.w_dequant[o]), 1.0f / CD_FRAC);
     const int C8 = C >> 3, total8 = a.kvol * a.cout * C8;
     for (int t = wb * 256 + threadIdx.x; t < total8; t += nwb * 256) {
         const int ko = t / C8, c0 = (t - ko * C8) * 8;
-        const i32x2v wv = *reinterpret_cast<const i32x2v *>(a.w + (size_t)ko * C + c0);
-        f16x8 hi, lo;
+        const int2 wv = *reinterpret_cast<const int2 *>(a.w + (size_t)ko * C + c0);
+        unsigned d[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int code = (int)(signed char)((i < 4 ? wv.x : wv.y) >> (8 * (i & 3)));
             const float rel = __fdiv_rn(s_dq[c0 + i], S);
-            float v = __fmul_rn((float)code, rel);
-            // v has to exist as ONE rounded fp32 value: without the barrier the backend folds (half)(code * rel) into a
-            // mixed-precision fma (v_fma_mixlo_f16, a single rounding of the exact product) for one use of `h` and keeps
-            // cvt(fp32 product) for the other — hi + lo then misses v by an fp16 ulp of hi (seen as 3e-2 absolute on |W'| ~ 100)
-            asm volatile("" : "+v"(v));
-            const _Float16 h = (_Float16)v;
-            hi[i] = h;
-            lo[i] = (_Float16)__fsub_rn(v, (float)h);
+            int v = (int)rintf(__fmul_rn(__fmul_rn((float)code, rel), CD_FRAC));      // |v| <= 127 * 2^16 < 2^23: exact
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int dig = (int)(signed char)(v & 0xff);      // balanced digit in [-128, 127]
+                d[p][i >> 2] |= (unsigned)(dig & 0xff) << (8 * (i & 3));
+                v = (v - dig) >> 8;
+            }
         }
-        *reinterpret_cast<f16x8 *>(a.wp + ((size_t)ko * 2 + 0) * C + c0) = hi;
-        *reinterpret_cast<f16x8 *>(a.wp + ((size_t)ko * 2 + 1) * C + c0) = lo;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            *reinterpret_cast<uint2 *>(a.wp + ((size_t)ko * 3 + p) * C + c0) = make_uint2(d[p][0], d[p][1]);
     }
 }
 
 // ------------------------------------------------------------------ conv kernels
 struct SpCodedArgs {
     const int8_t *codes;      // [cap_in][CIN]
-    const _Float16 *wp;       // [kvol][COUT][2][CIN]
+    const int8_t *wp;         // [kvol][COUT][3][CIN]
     const float *out_mul;     // [COUT]
     const float *bias, *post_scale, *post_shift, *residual;
     const int *nbr;           // [cap_out][kvol]
@@ -155,33 +134,93 @@ struct SpCodedArgs {
     unsigned codes_bytes;
     // static PTQ: the consumer's quantiser runs in this epilogue (its calibrated scale is a constant): codes of the output rows
     const float *next_scale;  // [COUT] qmax / amax_c of the consumer (0 for a dead channel), or nullptr
-    int8_t *next_codes;       // [cap_out][COUT] in the consumer's code layout
+    int8_t *next_codes;       // [cap_out][COUT]
     float next_qmax;
     int skip_f32;             // nobody reads the fp32 rows (no residual / feature-map use): do not store them
 };
 
 // TensorQuantizer with a calibrated amax: clamp(rint(v * scale), -qmax - 1, qmax) — the arithmetic of sp_prep_kernel
-__device__ __forceinline__ signed char cd_static_code(float v, float scale, float qmax) {
+__device__ __forceinline__ int cd_static_code(float v, float scale, float qmax) {
     float q = rintf(__fmul_rn(v, scale));
     q = fminf(fmaxf(q, -qmax - 1.f), qmax);
-    return (signed char)(int)q;
+    return (int)q;
 }
 
-// Cin = 16: K chunk = 2 kernel offsets x 16 channels; lane (l15, g) holds 8 channels of offset 2q + (g >> 1).
-template <int COUT, int KVOL, int NW, int PL>
+// XOR swizzle of the four 16-byte chunks of a 64-byte LDS row: conflict-free for the hardware's ds_read_b128 lane groups when
+// lane l15 reads row l15 (csrc/conv2d.hip uses the same map)
+__device__ __forceinline__ int cd_swz(int row, int chunk) { return chunk ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3); }
+
+// Per-channel epilogue operands staged in LDS: [5][CT] = out_mul, bias, post_scale, post_shift, next_scale
+template <int CT>
+__device__ __forceinline__ void cd_stage_epilogue(const SpCodedArgs &a, int ob, float *ep, int tid, int nth) {
+    for (int t = tid; t < 5 * CT; t += nth) {
+        const int f = t / CT, o = ob + (t - f * CT);
+        float v = f == 0 ? a.out_mul[o] : (f == 1 ? (a.bias ? a.bias[o] : 0.f) : (f == 2 ? (a.post_scale ? a.post_scale[o] : 1.f)
+                         : (f == 3 ? (a.post_shift ? a.post_shift[o] : 0.f) : (a.next_codes ? a.next_scale[o] : 0.f))));
+        ep[t] = v;
+    }
+}
+
+// One 16-channel x 16-row accumulator tile -> output: lane (l15 = row, g) holds channels 4g .. 4g+3. PL planes, plane 0 least
+// significant of those multiplied (the multiplier carries 256^(3 - PL)). Returns the lane's |y| maxima of its four channels.
+template <int PL, int CT, int COUT>
+__device__ __forceinline__ f32x4v cd_emit_tile(const SpCodedArgs &a, const i32x4v (&acc)[PL], const float *ep, int cl, int ob, int m,
+                                               bool live) {
+    const f32x4v mul = *reinterpret_cast<const f32x4v *>(ep + 0 * CT + cl);
+    const f32x4v bs = *reinterpret_cast<const f32x4v *>(ep + 1 * CT + cl);
+    const f32x4v ps = *reinterpret_cast<const f32x4v *>(ep + 2 * CT + cl);
+    const f32x4v pt = *reinterpret_cast<const f32x4v *>(ep + 3 * CT + cl);
+    const f32x4v ns = *reinterpret_cast<const f32x4v *>(ep + 4 * CT + cl);
+    f32x4v out = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    if (!live) return out;
+    f32x4v res = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    if (a.residual) res = *reinterpret_cast<const f32x4v *>(a.residual + (size_t)m * COUT + ob + cl);
+    int packed = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float s = (float)acc[PL - 1][r];
+#pragma unroll
+        for (int p = PL - 2; p >= 0; --p) s = __fmaf_rn(s, 256.0f, (float)acc[p][r]);      // exact up to fp32 rounding of the sum
+        if (PL == 2) s = __fmul_rn(s, 256.0f);             // planes d2 d1 only: the multiplier is the three-plane one
+        float v = __fmul_rn(s, mul[r]);
+        if (a.bias) v = __fadd_rn(v, bs[r]);
+        if (a.post_scale) v = __fadd_rn(__fmul_rn(v, ps[r]), pt[r]);
+        if (a.residual) v = __fadd_rn(v, res[r]);
+        if (a.relu) v = fmaxf(v, 0.f);
+        out[r] = v;
+        if (a.next_codes) packed |= (cd_static_code(v, ns[r], a.next_qmax) & 0xff) << (8 * r);
+    }
+    if (!a.skip_f32) *reinterpret_cast<f32x4v *>(a.feats_out + (size_t)m * COUT + ob + cl) = out;
+    if (a.next_codes) *reinterpret_cast<int *>(a.next_codes + (size_t)m * COUT + ob + cl) = packed;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[r] = fabsf(out[r]);
+    return out;
+}
+
+// max over the 16 lanes that share g (the rows of a tile), result in every lane
+__device__ __forceinline__ float cd_max16(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, __shfl_xor(v, 4, 64));
+    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    return v;
+}
+
+// Cin = 16. K step q = kernel offsets 3q, 3q+1, 3q+2 (one (kz, ky) row of the 3x3x3 kernel) x 16 channels + an idle slot:
+// lane (l15 = row, g) gathers the whole 16-byte code row of its neighbour at offset 3q + g.
+template <int COUT, int NW, int PL>
 __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
-    constexpr int CIN = 16;
+    constexpr int CIN = 16, KVOL = 27, NQ = 9;
     constexpr int NTH = 64 * NW, TMW = 16 * NW;
     constexpr int NT = COUT / 16;
-    constexpr int KT = KVOL * CIN;
-    constexpr int NCH = (KT + 31) / 32;
-    constexpr int LD = NCH * 32 + 8;                     // halves per LDS weight row (16-byte pad)
+    constexpr int LDR = NQ * 64 + 16;                     // bytes per LDS weight row (plane, channel): 9 K steps + pad
+    constexpr int P0 = CD_PLANES - PL;                    // first plane multiplied
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16 *Bh = reinterpret_cast<_Float16 *>(smem_raw);          // [COUT][LD] hi, K index = offset * CIN + channel
-    _Float16 *Bl = Bh + COUT * LD;                                   // [COUT][LD] lo (PL == 2 only)
-    float *red = reinterpret_cast<float *>(Bh + PL * COUT * LD);     // [NW][COUT]
-    constexpr int NPW = 16 * KVOL;                                   // gather-table entries of a wave's 16 rows: contiguous in memory
-    int *nbr_s = reinterpret_cast<int *>(red + NW * COUT) + (threadIdx.x >> 6) * NPW;     // [NW][16 * KVOL], this wave's slice
+    unsigned char *Wl = smem_raw;                                        // [PL][COUT][LDR]
+    float *ep = reinterpret_cast<float *>(Wl + PL * COUT * LDR);         // [5][COUT]
+    float *red = ep + 5 * COUT;                                          // [NW][COUT]
+    constexpr int NPW = 16 * KVOL;                                       // gather-table entries of a wave's 16 rows: contiguous in memory
+    int *nbr_s = reinterpret_cast<int *>(red + NW * COUT) + (threadIdx.x >> 6) * NPW;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
@@ -191,30 +230,19 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
     const auto rsrc_f = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, (int)a.codes_bytes, 0x00020000);
     const auto rsrc_n = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, a.cap_out * KVOL * 4, 0x00020000);
 
-    // per-channel epilogue operands and the guard of the final atomic max: fetched before the weight staging, not at the tail
-    float e_mul[NT], e_b[NT], e_ps[NT], e_pt[NT], e_nsc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int o = nt * 16 + l15;
-        e_mul[nt] = a.out_mul[o];
-        e_b[nt] = a.bias ? a.bias[o] : 0.f;
-        e_ps[nt] = a.post_scale ? a.post_scale[o] : 1.f;
-        e_pt[nt] = a.post_shift ? a.post_shift[o] : 0.f;
-        e_nsc[nt] = a.next_codes ? a.next_scale[o] : 0.f;
-    }
     float amax_seen = (a.absmax_out && tid < COUT) ? a.absmax_out[tid] : 0.f;
-    for (int t = tid; t < PL * COUT * (LD / 8); t += NTH) {
-        const int pl = t / (COUT * (LD / 8)), r = t % (COUT * (LD / 8));
-        const int o = r / (LD / 8), kk = (r % (LD / 8)) * 8;
+    cd_stage_epilogue<COUT>(a, 0, ep, tid, NTH);
+    // planes -> LDS: item = (plane, channel, K step, slot): 16 bytes = the 16 input channels of one kernel offset
+    for (int t = tid; t < PL * COUT * NQ * 4; t += NTH) {
+        const int s4 = t & 3, q = (t >> 2) % NQ, r = (t >> 2) / NQ;       // r = pl * COUT + o
+        const int pl = r / COUT, o = r - pl * COUT;
         i32x4v v = (i32x4v){0, 0, 0, 0};
-        if (kk < KT) v = *reinterpret_cast<const i32x4v *>(a.wp + (((size_t)(kk / CIN) * COUT + o) * 2 + pl) * CIN + (kk % CIN));
-        *reinterpret_cast<i32x4v *>((pl ? Bl : Bh) + o * LD + kk) = v;
+        if (s4 < 3) v = *reinterpret_cast<const i32x4v *>(a.wp + ((size_t)((3 * q + s4) * COUT + o) * CD_PLANES + P0 + pl) * CIN);
+        *reinterpret_cast<i32x4v *>(Wl + r * LDR + q * 64 + s4 * 16) = v;
     }
     __syncthreads();
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        // rulebook tile through LDS: the wave's 16 x KVOL gather-table entries are one contiguous block, loaded coalesced (7 dwords
-        // per lane) instead of KVOL strided 4-byte loads per lane, of which a lane uses every other one
         const int rbase = tile * TMW + wave * 16;
         __syncthreads();                                 // the previous tile's reads of nbr_s are done
 #pragma unroll
@@ -227,63 +255,43 @@ __global__ __launch_bounds__(64 * NW) void spconv_cd_kernel(SpCodedArgs a) {
             }
         }
         __syncthreads();
-        f32x4 acc[NT];
+        i32x4v acc[NT][PL];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int bofs = l15 * LD + 8 * g;
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-        for (int q = 0; q < NCH; ++q) {
-            const int j = 2 * q + (g >> 1);              // kernel offset of this lane's half of the K chunk
-            const int idx = j < KVOL ? nbr_s[l15 * KVOL + (j < KVOL ? j : KVOL - 1)] : -1;
-            const unsigned off = idx >= 0 ? (unsigned)(idx * CIN + (g & 1) * 8) : CD_OOB;
-            const i32x2v cv = __builtin_amdgcn_raw_buffer_load_b64(rsrc_f, off, 0, 0);   // no neighbour: out of range, no traffic
-            // none of the wave's 16 rows has a neighbour at these two offsets: skip the conversion, the LDS reads and the
-            // MFMAs — adding exact zeros changes nothing
+            for (int p = 0; p < PL; ++p) acc[i][p] = (i32x4v){0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int idx = g < 3 ? nbr_s[l15 * KVOL + 3 * q + (g < 3 ? g : 0)] : -1;
+            const unsigned off = idx >= 0 ? (unsigned)(idx * CIN) : CD_OOB;
+            const i32x4v cv = __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, off, 0, 0);   // no neighbour: out of range, no traffic
+            // none of the wave's 16 rows has a neighbour in this (kz, ky) row: skip the LDS reads and the MFMAs
             if (__builtin_amdgcn_ballot_w64(idx >= 0) != 0ull) {
-                const f16x8 fa = cd_cvt8(cv.x, cv.y);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const f16x8 fh = *reinterpret_cast<const f16x8 *>(Bh + bofs + nt * 16 * LD + q * 32);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fh, acc[nt], 0, 0, 0);
-                    if (PL == 2) {
-                        const f16x8 fl = *reinterpret_cast<const f16x8 *>(Bl + bofs + nt * 16 * LD + q * 32);
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fl, acc[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int p = 0; p < PL; ++p) {
+                        const i32x4v wf = *reinterpret_cast<const i32x4v *>(Wl + (p * COUT + nt * 16 + l15) * LDR + q * 64 + g * 16);
+                        acc[nt][p] = __builtin_amdgcn_mfma_i32_16x16x64_i8(wf, cv, acc[nt][p], 0, 0, 0);
                     }
-                }
             }
         }
-        // epilogue (D layout: col = lane&15 -> out channel, row = 4g + reg)
-        float cmax[NT];
+        // epilogue: lane (l15 = row, g) holds channels nt * 16 + 4g .. + 3
+        const int m = rbase + l15;
+        float cmax[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int o = nt * 16 + l15;
-            const float mul = e_mul[nt], b = e_b[nt], ps = e_ps[nt], pt = e_pt[nt], nsc = e_nsc[nt];
-            const int npos = cd_code_pos(o, COUT);
-            float mx = 0.f;
+            const f32x4v mx = cd_emit_tile<PL, COUT, COUT>(a, acc[nt], ep, nt * 16 + 4 * g, 0, m, m < n);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int tr = tile * TMW + wave * 16 + 4 * g + r;
-                if (tr < n) {
-                    const int m = tr;
-                    float v = __fmul_rn(acc[nt][r], mul);
-                    if (a.bias) v = __fadd_rn(v, b);
-                    if (a.post_scale) v = __fadd_rn(__fmul_rn(v, ps), pt);
-                    if (a.residual) v = __fadd_rn(v, a.residual[(size_t)m * COUT + o]);
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (!a.skip_f32) a.feats_out[(size_t)m * COUT + o] = v;
-                    if (a.next_codes) a.next_codes[(size_t)m * COUT + npos] = cd_static_code(v, nsc, a.next_qmax);
-                    mx = fmaxf(mx, fabsf(v));
-                }
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            cmax[nt] = mx;
+            for (int r = 0; r < 4; ++r) cmax[nt][r] = cd_max16(mx[r]);
         }
         if (a.absmax_out) {
             __syncthreads();
-            if (g == 0) {
+            if (l15 == 0) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) red[wave * COUT + nt * 16 + l15] = cmax[nt];
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) red[wave * COUT + nt * 16 + 4 * g + r] = cmax[nt][r];
             }
             __syncthreads();
             if (tid < COUT) {       // COUT <= 64 * NW; guard read at kernel start (stale and lower only costs a redundant atomic)
@@ -312,33 +320,32 @@ extern "C" int aq3d_diag_set_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP
 #define CW_ACC(acc, from, to)
 #endif
 
-// Cin >= 32. Unit of work = (kernel offset k, 64-channel slice h) [32 channels when Cin = 32]: the two W' planes of the
-// slice go through LDS (double buffered, XOR-swizzled 128-byte rows as in the round-1 wide kernel), the A fragments of the
-// wave's two 16-row tiles are gathered straight into registers: ONE bounded buffer load per row and unit (16 bytes = the
-// 8 + 8 channels of the lane's two K chunks; 8 bytes when Cin = 32), missing neighbour = out-of-range offset = zeros.
-template <int CIN, int COUT, int CT, int RT, int FD, int PL>
-__global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
+// Cin >= 32. Unit of work = 64 K elements: a 64-channel slice of one kernel offset (Cin >= 64) or TWO kernel offsets x 32
+// channels (Cin = 32). The unit's planes go through LDS (double buffered, XOR-swizzled 64-byte rows), the codes of the wave's
+// row tiles are gathered straight into MFMA B operands: ONE bounded 16-byte buffer load per row and unit.
+template <int CIN, int COUT, int CT, int RT, int FD, int PL, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void spconv_cw_kernel(SpCodedArgs a) {
     constexpr int NCB = COUT / CT;                      // column blocks: a workgroup computes CT of the COUT output channels
-    constexpr int TM = 4 * RT * 16;
+    constexpr int NTH = 64 * NW;                         // NW waves, RT 16-row tiles each
+    constexpr int TM = NW * RT * 16;
     constexpr int NT = CT / 16;
-    // A unit is 64 K elements: a 64-channel slice of one kernel offset (Cin >= 64) or TWO kernel offsets x 32 channels (Cin = 32:
-    // K chunk 0 = first offset, chunk 1 = second; half as many staging rounds and barriers as one offset per unit).
     constexpr bool PAIR = CIN == 32;
-    constexpr int UC = 64;
-    constexpr int NU = PAIR ? 1 : CIN / UC;
-    constexpr int KC = 2;
-    constexpr bool SWZ = true;
-    constexpr int LDW = UC;                              // halves per LDS weight row of one plane (XOR-swizzled 16-byte chunks)
-    constexpr int PCH = CT * UC / 8;                  // 16-byte chunks of one plane of a unit
-    constexpr int WCH = PL * PCH;                        // PL = 2: hi | lo planes of W'; 1: the hi plane only (AQ3D_FLAG_W_FP16)
-    constexpr int NWL = (WCH + 255) / 256;
+    constexpr int UB = CIN >= 128 ? 128 : 64;           // K bytes of a unit per row: at Cin = 128 a unit is one whole kernel offset (a
+    constexpr int KS = UB / 64;                          // code row = one full 128-byte line per gather, half as many barriers)
+    constexpr int NU = PAIR ? 1 : CIN / UB;
+    constexpr int ROWS = PL * CT;                        // LDS rows of one unit: (plane, channel), UB bytes each
+    constexpr int CPR = UB / 16;                         // 16-byte chunks per row
+    constexpr int WCH = ROWS * CPR;                      // 16-byte chunks of one unit
+    constexpr int NWL = (WCH + NTH - 1) / NTH;
+    constexpr int P0 = CD_PLANES - PL;
     static_assert((CIN == 32 || CIN % 64 == 0) && CT % 16 == 0 && COUT % CT == 0, "channel granularity");
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    _Float16 *Wb = reinterpret_cast<_Float16 *>(smem_raw);              // [2 buffers][PL planes][CT][LDW]
-    int *nbr_s = reinterpret_cast<int *>(Wb + 2 * PL * CT * LDW);          // [TM][kvol]
-    float *red = reinterpret_cast<float *>(nbr_s + TM * 27);            // [4][CT]
-    int *mask_s = reinterpret_cast<int *>(red + 4 * CT);
+    unsigned char *Wb = smem_raw;                                          // [2 buffers][ROWS][64]
+    int *nbr_s = reinterpret_cast<int *>(Wb + 2 * ROWS * UB);              // [TM][kvol]
+    float *ep = reinterpret_cast<float *>(nbr_s + TM * 27);               // [5][CT]
+    float *red = ep + 5 * CT;                                              // [NW][CT]
+    int *mask_s = reinterpret_cast<int *>(red + NW * CT);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, l15 = lane & 15;
@@ -355,33 +362,21 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
     unsigned long long s_cvt = 0, s_mfma = 0, s_store = 0, s_bar = 0;
 #endif
     const auto rsrc_f = __builtin_amdgcn_make_buffer_rsrc((void *)a.codes, 0, (int)a.codes_bytes, 0x00020000);
-    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.wp, 0, kvol * COUT * 2 * CIN * 2, 0x00020000);
 
-    // the per-channel epilogue operands are fetched now: loading them after the unit loop put one more global round trip at the
-    // end of every workgroup (stamps, scratch/cw_stamps.py: prologue + epilogue were 45 % of the 32-channel kernel, 34 % at 64)
     const float amax_seen = (a.absmax_out && tid < CT) ? a.absmax_out[ob + tid] : 0.f;      // guard of the final atomic max
-    float e_mul[NT], e_bs[NT], e_ps[NT], e_pt[NT], e_nsc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int o = ob + nt * 16 + l15;
-        e_mul[nt] = a.out_mul[o];
-        e_bs[nt] = a.bias ? a.bias[o] : 0.f;
-        e_ps[nt] = a.post_scale ? a.post_scale[o] : 1.f;
-        e_pt[nt] = a.post_shift ? a.post_shift[o] : 0.f;
-        e_nsc[nt] = a.next_codes ? a.next_scale[o] : 0.f;
-    }
+    cd_stage_epilogue<CT>(a, ob, ep, tid, NTH);
     // gather-table tile -> LDS with 16-byte loads; the 27-bit "some row has this neighbour" mask is built from the loaded values
     // (OR over the wave by shuffles, one LDS word per wave) instead of a second pass over the staged table behind a barrier
     {
         const int rows = n - row0 < TM ? n - row0 : TM;
-        const int lim = rows * kvol, total = TM * kvol;                       // total % 4 == 0 (TM = 128)
+        const int lim = rows * kvol, total = TM * kvol;                       // total % 4 == 0 (TM a multiple of 128)
         const int alloc = (a.cap_out - row0 < TM ? a.cap_out - row0 : TM) * kvol;    // dwords of the table that exist from row0 on
         const int *src = a.nbr + (size_t)row0 * kvol;
-        constexpr int NQ = (TM * 27 / 4 + 255) / 256;
+        constexpr int NQ = (TM * 27 / 4 + NTH - 1) / NTH;
         i32x4v v[NQ];
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int t4 = (tid + 256 * i) * 4;
+            const int t4 = (tid + NTH * i) * 4;
             v[i] = (i32x4v){-1, -1, -1, -1};
             if (t4 + 3 < alloc) v[i] = *reinterpret_cast<const i32x4v *>(src + t4);
             else if (t4 < alloc) {
@@ -393,7 +388,7 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
         int bits = 0;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            const int t4 = (tid + 256 * i) * 4;
+            const int t4 = (tid + NTH * i) * 4;
             if (t4 < total) {
                 int kk = t4 % kvol;
                 int e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
@@ -411,36 +406,39 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
         if (lane == 0) mask_s[wave] = bits;
     }
     __syncthreads();
-    const int live = mask_s[0] | mask_s[1] | mask_s[2] | mask_s[3];
+    int live = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) live |= mask_s[w];
 
-    f32x4 acc[RT][NT];
+    i32x4v acc[RT][NT][PL];
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int p = 0; p < PL; ++p) acc[rt][nt][p] = (i32x4v){0, 0, 0, 0};
 
-    i32x4v A0[RT], A1[RT], wn[NWL];
-    // chunk t of a unit: plane = t / PCH, row o, 16-byte chunk c8 of the UC-channel slice
-    auto loadW = [&](int k, int h, int k2) {
+    i32x4v A0[RT][KS], A1[RT][KS];
+    // XOR swizzle of a row's 16-byte chunks, conflict-free for the ds_read_b128 lane groups when lane l15 reads row l15:
+    // 64-byte rows: cd_swz; 128-byte rows: chunk ^ ((row >> 1) & 7)
+    auto swz = [](int row, int chunk) { return UB == 64 ? cd_swz(row, chunk) : (chunk ^ ((row >> 1) & 7)); };
+    // The planes of a unit go global -> LDS by LDS-DMA (no register round trip, no ds_write pass): the LDS image is lane-linear per
+    // wave instruction (slot t = 16-byte chunk c of LDS row r = plane * CT + channel), so the XOR swizzle the fragment reads apply
+    // sits on the SOURCE address: slot (r, c) receives chunk swz(r, c) of the row (cdna_hip_programming.md rule 21).
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    auto stageW = [&](int b, int k, int h, int k2) {
+        if (k >= kvol) return;                           // no next unit (wave-uniform): the idle unit multiplies zero codes
 #pragma unroll
         for (int i = 0; i < NWL; ++i) {
-            const int t = tid + 256 * i;
-            const int pl = t / PCH, r = t % PCH;
-            const int c8 = r % (UC / 8), o = r / (UC / 8);
-            const unsigned off = PAIR ? (unsigned)(((((c8 < 4 ? k : k2) * COUT + ob + o) * 2 + pl) * CIN + (c8 & 3) * 8) * 2)
-                                      : (unsigned)((((k * COUT + ob + o) * 2 + pl) * CIN + h * UC + c8 * 8) * 2);
-            if (WCH % 256 == 0 || t < WCH)
-                wn[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, off, 0, 0);   // k = kvol is past the end of the tensor: zeros
-        }
-    };
-    auto storeW = [&](int b) {
-#pragma unroll
-        for (int i = 0; i < NWL; ++i) {
-            const int t = tid + 256 * i;
-            const int pl = t / PCH, r = t % PCH;
-            const int c8 = r % (UC / 8), o = r / (UC / 8);
-            if (WCH % 256 == 0 || t < WCH)
-                *reinterpret_cast<i32x4v *>(Wb + ((b * PL + pl) * CT + o) * LDW + (SWZ ? (c8 ^ ((o >> 1) & 7)) : c8) * 8) = wn[i];
+            const int t = tid + NTH * i;
+            const int r = t / CPR, c = swz(r, t % CPR);
+            const int pl = r / CT, o = r - pl * CT;
+            const int kk = PAIR ? (c < 2 ? k : (k2 < kvol ? k2 : k)) : k;        // k2 = kvol: its codes are zeros, any bytes do
+            const size_t off = PAIR ? (size_t)((kk * COUT + ob + o) * CD_PLANES + P0 + pl) * CIN + (c & 1) * 16
+                                    : (size_t)((kk * COUT + ob + o) * CD_PLANES + P0 + pl) * CIN + h * UB + c * 16;
+            if (WCH % NTH == 0 || t < WCH)
+                __builtin_amdgcn_global_load_lds((gptr_t *)(a.wp + off), (lptr_t *)(Wb + (size_t)(b * ROWS) * UB + t * 16), 16, 0, 0);
         }
     };
     auto readSrc = [&](int (&src)[RT], int k) {
@@ -451,24 +449,19 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
             src[rt] = k < kvol ? v : -1;
         }
     };
-    auto loadA1 = [&](i32x4v (&A)[RT], const int (&src)[RT], const int (&src2)[RT], int h, int rt) {
-        if (!PAIR) {
-            const unsigned off = src[rt] >= 0 ? (unsigned)src[rt] * (unsigned)CIN + (unsigned)(h * 64 + 16 * g) : CD_OOB;
-            A[rt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, off, 0, 0);
-        } else {    // 8 channels of the lane's K group from each of the unit's two kernel offsets
-            const unsigned off = src[rt] >= 0 ? (unsigned)src[rt] * (unsigned)CIN + (unsigned)(8 * g) : CD_OOB;
-            const unsigned off2 = src2[rt] >= 0 ? (unsigned)src2[rt] * (unsigned)CIN + (unsigned)(8 * g) : CD_OOB;
-            const i32x2v v = __builtin_amdgcn_raw_buffer_load_b64(rsrc_f, off, 0, 0);
-            const i32x2v v2 = __builtin_amdgcn_raw_buffer_load_b64(rsrc_f, off2, 0, 0);
-            A[rt] = (i32x4v){v.x, v.y, v2.x, v2.y};
-        }
+    // B operand of row tile rt, K step ks: lane (l15 = row, g) takes K bytes 64 ks + 16g .. + 15 of the unit
+    auto loadA1 = [&](i32x4v (&A)[RT][KS], const int (&src)[RT], const int (&src2)[RT], int h, int q) {
+        const int rt = q / KS, ks = q % KS;
+        const int s = PAIR ? (g < 2 ? src[rt] : src2[rt]) : src[rt];
+        const unsigned off = s >= 0 ? (unsigned)s * (unsigned)CIN + (unsigned)(PAIR ? (g & 1) * 16 : h * UB + ks * 64 + 16 * g) : CD_OOB;
+        A[rt][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, off, 0, 0);
     };
-    auto loadA = [&](i32x4v (&A)[RT], int k, int h, int k2) {
+    auto loadA = [&](i32x4v (&A)[RT][KS], int k, int h, int k2) {
         int src[RT], src2[RT];
         readSrc(src, k);
         readSrc(src2, PAIR ? k2 : kvol);
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) loadA1(A, src, src2, h, rt);
+        for (int q = 0; q < RT * KS; ++q) loadA1(A, src, src2, h, q);
     };
     auto next_live = [&](int k) {
         if (k >= kvol) return kvol;
@@ -482,31 +475,21 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
         k = next_live(PAIR ? k2 : k);
         if (PAIR) k2 = next_live(k);
     };
-    auto unit = [&](i32x4v (&Acur)[RT], i32x4v (&Anext)[RT], int b, int &k, int &h, int &k2) {
+    auto unit = [&](i32x4v (&Acur)[RT][KS], i32x4v (&Anext)[RT][KS], int b, int &k, int &h, int &k2) {
         CW_STAMP(ta);
         next_unit(k, h, k2);                             // (k, h, k2) now names the NEXT unit
-        loadW(k, h, k2);
-        f16x8 F[RT][KC];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-            F[rt][0] = cd_cvt8(Acur[rt].x, Acur[rt].y);
-            F[rt][1] = cd_cvt8(Acur[rt].z, Acur[rt].w);
-        }
-#ifdef AQ3D_STAMPS
-        asm volatile("" :: "v"(F[0][0]), "v"(F[RT - 1][1]));
-#endif
+        stageW(b ^ 1, k, h, k2);                         // its planes land in the other buffer while this unit multiplies
         CW_STAMP(tb);
-        // fragment j = (kc * NT + nt) * PL + plane: read FD ahead of the MFMAs that use it, each feeds RT MFMAs
-        constexpr int NF = KC * NT * PL;
-        constexpr int LA = NF - 1 < RT ? NF - 1 : RT;        // next unit's A loads issued inside the MFMA loop (the rest after it)
-        const int c0 = SWZ ? (g ^ ((l15 >> 1) & 7)) : g;
-        const _Float16 *bb = Wb + (b * PL * CT + l15) * LDW;
+        // fragment j = (nt * PL + plane) * KS + ks: read FD ahead of the MFMAs that use it, each feeds RT MFMAs
+        constexpr int NF = NT * PL * KS;
+        constexpr int NA = RT * KS;                          // gathers of the next unit
+        constexpr int LA = NF - 1 < NA ? NF - 1 : NA;        // ... issued inside the MFMA loop (the rest after it)
+        const unsigned char *bb = Wb + (size_t)(b * ROWS + l15) * UB;
         auto frag = [&](int j) {
-            const int pl = j % PL, nt = (j / PL) % NT, kc = (j / PL) / NT;
-            const int c = SWZ ? (c0 ^ (kc * 4)) : (c0 + kc * 4);
-            return *reinterpret_cast<const f16x8 *>(bb + (pl * CT + nt * 16) * LDW + c * 8);
+            const int ks = j % KS, pl = (j / KS) % PL, nt = j / (KS * PL);
+            return *reinterpret_cast<const i32x4v *>(bb + (pl * CT + nt * 16) * UB + swz(l15, ks * 4 + g) * 16);
         };
-        f16x8 fb[FD + 1];
+        i32x4v fb[FD + 1];
 #pragma unroll
         for (int j = 0; j < FD && j < NF; ++j) fb[j] = frag(j);
         int src[RT], src2[RT];
@@ -518,18 +501,17 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
             if (j + FD < NF) fb[(j + FD) % (FD + 1)] = frag(j + FD);
             if (j >= 1 && j <= LA) loadA1(Anext, src, src2, h, j - 1);
             __builtin_amdgcn_sched_barrier(0);
-            const int nt = (j / PL) % NT, kc = (j / PL) / NT;
-            const f16x8 f = fb[j % (FD + 1)];
+            const int ks = j % KS, pl = (j / KS) % PL, nt = j / (KS * PL);
+            const i32x4v f = fb[j % (FD + 1)];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(F[rt][kc], f, acc[rt][nt], 0, 0, 0);
+            for (int rt = 0; rt < RT; ++rt) acc[rt][nt][pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f, Acur[rt][ks], acc[rt][nt][pl], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int rt = LA; rt < RT; ++rt) loadA1(Anext, src, src2, h, rt);
+        for (int q = LA; q < NA; ++q) loadA1(Anext, src, src2, h, q);
         CW_STAMP(tc);
-        storeW(b ^ 1);
         CW_STAMP(td);
-        __syncthreads();
+        __syncthreads();                                 // drains the LDS-DMA (vmcnt) and the next unit's gathers
         CW_STAMP(te);
         CW_ACC(s_cvt, ta, tb); CW_ACC(s_mfma, tb, tc); CW_ACC(s_store, tc, td); CW_ACC(s_bar, td, te);
     };
@@ -538,9 +520,8 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
     int k = live ? (__ffs(live) - 1) : kvol, h = 0;
     int k2 = PAIR ? next_live(k) : kvol;
     const int nunits = PAIR ? (__popc(live) + 1) / 2 : __popc(live) * NU;
-    loadW(k, h, k2);
+    stageW(0, k, h, k2);
     loadA(A0, k, h, k2);
-    storeW(0);
     __syncthreads();
     CW_STAMP(t_fill);
     for (int u = 0; u < nunits; u += 2) {
@@ -549,56 +530,44 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
     }
     CW_STAMP(t_loop);
 
-    // ---- epilogue (D layout: col = lane&15 -> out channel, row = 4g + reg -> tile row)
-    int mrow[RT][4];
+    // ---- epilogue: lane (l15 = row of the tile, g) holds channels ob + nt * 16 + 4g .. + 3
+    float cmax[NT][4];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int tr = row0 + wave * (RT * 16) + rt * 16 + 4 * g + r;
-            mrow[rt][r] = tr < n ? tr : -1;
+        for (int r = 0; r < 4; ++r) cmax[nt][r] = 0.f;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int m = row0 + wave * (RT * 16) + rt * 16 + l15;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4v mx = cd_emit_tile<PL, CT, COUT>(a, acc[rt][nt], ep, nt * 16 + 4 * g, ob, m, m < n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cmax[nt][r] = fmaxf(cmax[nt][r], mx[r]);
         }
-    float cmax[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int o = ob + nt * 16 + l15;
-        const float mul = e_mul[nt], bs = e_bs[nt], ps = e_ps[nt], pt = e_pt[nt], nsc = e_nsc[nt];
-        const int npos = cd_code_pos(o, COUT);
-        float mx = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mrow[rt][r];
-                if (m >= 0) {
-                    float v = __fmul_rn(acc[rt][nt][r], mul);
-                    if (a.bias) v = __fadd_rn(v, bs);
-                    if (a.post_scale) v = __fadd_rn(__fmul_rn(v, ps), pt);
-                    if (a.residual) v = __fadd_rn(v, a.residual[(size_t)m * COUT + o]);
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    if (!a.skip_f32) a.feats_out[(size_t)m * COUT + o] = v;
-                    if (a.next_codes) a.next_codes[(size_t)m * COUT + npos] = cd_static_code(v, nsc, a.next_qmax);
-                    mx = fmaxf(mx, fabsf(v));
-                }
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        cmax[nt] = mx;
     }
     if (a.absmax_out) {
-        if (g == 0) {
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) red[wave * CT + nt * 16 + l15] = cmax[nt];
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cmax[nt][r] = cd_max16(cmax[nt][r]);
+        if (l15 == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave * CT + nt * 16 + 4 * g + r] = cmax[nt][r];
         }
         __syncthreads();
         if (tid < CT) {     // CT <= 256; the guard value was read at kernel start (a stale, lower value only costs a redundant atomic)
-            const float mx = fmaxf(fmaxf(red[tid], red[CT + tid]), fmaxf(red[2 * CT + tid], red[3 * CT + tid]));
+            float mx = red[tid];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) mx = fmaxf(mx, red[w * CT + tid]);
             if (mx > amax_seen) aq3d_atomic_max_pos(&a.absmax_out[ob + tid], mx);
         }
     }
 #ifdef AQ3D_STAMPS
     if (lane == 0 && g_cw_stamps) {
-        unsigned long long *o = g_cw_stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+        unsigned long long *o = g_cw_stamps + ((size_t)blockIdx.x * NW + wave) * 8;
         const unsigned long long t_end = CW_NOW();
         o[0] = t_pro - t_start; o[1] = t_fill - t_pro; o[2] = s_cvt; o[3] = s_mfma; o[4] = s_store; o[5] = s_bar;
         o[6] = t_end - t_loop; o[7] = ((unsigned long long)nunits << 48) | (t_end - t_start);
@@ -607,30 +576,27 @@ __global__ __launch_bounds__(256) void spconv_cw_kernel(SpCodedArgs a) {
 }
 
 // ------------------------------------------------------------------ host side
-template <int COUT, int KVOL, int NW, int PL>
+template <int COUT, int NW, int PL>
 static int launch_cd(const SpCodedArgs &a, hipStream_t stream) {
-    constexpr int NCH = (KVOL * 16 + 31) / 32;
-    constexpr size_t lds = (size_t)PL * COUT * (NCH * 32 + 8) * 2 + NW * COUT * 4 + (size_t)NW * 16 * KVOL * 4;
+    constexpr size_t lds = (size_t)PL * COUT * (9 * 64 + 16) + (size_t)5 * COUT * 4 + (size_t)NW * COUT * 4 + (size_t)NW * 16 * 27 * 4;
     const int tiles = aq3d_div_up(a.cap_out, 16 * NW);
     const int grid = tiles < 2048 ? (tiles < 1 ? 1 : tiles) : 2048;
-    auto kern = spconv_cd_kernel<COUT, KVOL, NW, PL>;
+    auto kern = spconv_cd_kernel<COUT, NW, PL>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * NW), lds, stream, a);
     AQ3D_CHECK_LAUNCH("aq3d_spconv_coded(direct)");
     return AQ3D_OK;
 }
 
-template <int CIN, int COUT, int CT, int PL>
+template <int CIN, int COUT, int CT, int PL, int NW = 4>
 static int launch_cw(const SpCodedArgs &a, hipStream_t stream) {
-    // 2 row tiles per wave (RT), fragments read 4 ahead (FD): measured round 2 against RT = 1 / 4 and FD = 8 (all slower; RT = 1 also
-    // at Cin = 32: 29.4 against 27.9 us). W' loads two units ahead (second register set): no change (71.9 / 47.0 / 28.4 us) — removed.
     constexpr int RT = 2, FD = 4;
-    constexpr int TM = 64 * RT;
-    constexpr size_t lds = (size_t)2 * PL * CT * 64 * 2 + (size_t)TM * 27 * 4 + (size_t)4 * CT * 4 + 64;
+    constexpr int TM = NW * 16 * RT;
+    constexpr size_t lds = (size_t)2 * PL * CT * (CIN >= 128 ? 128 : 64) + (size_t)TM * 27 * 4 + (size_t)(5 + NW) * CT * 4 + 64;
     const int grid = aq3d_div_up(aq3d_div_up(a.cap_out, TM), 8) * 8 * (COUT / CT);
-    auto kern = spconv_cw_kernel<CIN, COUT, CT, RT, FD, PL>;
+    auto kern = spconv_cw_kernel<CIN, COUT, CT, RT, FD, PL, NW>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3(grid < 1 ? 1 : grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid < 1 ? 1 : grid), dim3(64 * NW), lds, stream, a);
     AQ3D_CHECK_LAUNCH("aq3d_spconv_coded(wide)");
     return AQ3D_OK;
 }
@@ -642,7 +608,7 @@ extern "C" int aq3d_spconv_coded_supported(int32_t cin, int32_t cout, int32_t kv
 }
 
 extern "C" size_t aq3d_spconv_wprep_bytes(int32_t cin, int32_t cout, int32_t kvol) {
-    return (size_t)kvol * cout * 2 * cin * sizeof(_Float16);
+    return (size_t)kvol * cout * CD_PLANES * cin;
 }
 
 extern "C" int aq3d_spconv_prep(const float *x, const float *amax, const int32_t *count, int32_t cap, int32_t C, int32_t bits,
@@ -652,13 +618,13 @@ extern "C" int aq3d_spconv_prep(const float *x, const float *amax, const int32_t
     const bool rows = x != nullptr, weights = weight_codes != nullptr;
     AQ3D_REQUIRE(amax && (rows || weights), "aq3d_spconv_prep: null argument");
     AQ3D_REQUIRE(!rows || (count && codes_out), "aq3d_spconv_prep: the row quantiser needs count and codes_out");
-    AQ3D_REQUIRE(!weights || (w_dequant && wprep_out && out_mul_out), "aq3d_spconv_prep: the weight copy needs w_dequant, wprep_out and out_mul_out");
-    AQ3D_REQUIRE(C >= 16 && C <= 256 && (C & 15) == 0 && bits >= 2 && bits <= 8, "aq3d_spconv_prep: C=%d bits=%d", C, bits);
+    AQ3D_REQUIRE(!weights || (w_dequant && wprep_out && out_mul_out), "aq3d_spconv_prep: the weight planes need w_dequant, wprep_out and out_mul_out");
+    AQ3D_REQUIRE(C >= 16 && C <= 256 && aq3d_is_pow2(C) && bits >= 2 && bits <= 8, "aq3d_spconv_prep: C=%d (a power of two in 16..256) bits=%d", C, bits);
     AQ3D_REQUIRE(cap > 0 && kvol >= 1 && kvol <= 27 && cout >= 1, "aq3d_spconv_prep: cap=%d kvol=%d cout=%d", cap, kvol, cout);
     AQ3D_REQUIRE((long long)cap * C < (1ll << 31), "aq3d_spconv_prep: cap * C overflows 32-bit indexing");
     SpPrepArgs a;
     a.x = x; a.amax = amax; a.count = count; a.cap = cap; a.C = C; a.qmax = (float)((1 << (bits - 1)) - 1);
-    a.per_tensor = per_tensor; a.codes = codes_out; a.w = weight_codes; a.w_dequant = w_dequant; a.wp = (_Float16 *)wprep_out;
+    a.per_tensor = per_tensor; a.codes = codes_out; a.w = weight_codes; a.w_dequant = w_dequant; a.wp = (int8_t *)wprep_out;
     a.out_mul = out_mul_out; a.kvol = kvol; a.cout = cout;
     a.row_blocks = rows ? aq3d_grid((int64_t)cap * C / 4, 256) : 0;
     const int wblocks = weights ? aq3d_grid((int64_t)kvol * cout * C / 8, 256, 256) : 0;
@@ -681,7 +647,7 @@ extern "C" int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void
         return AQ3D_ERR_UNSUPPORTED;
     }
     SpCodedArgs a;
-    a.codes = codes; a.wp = (const _Float16 *)wprep; a.out_mul = out_mul; a.bias = bias; a.post_scale = post_scale;
+    a.codes = codes; a.wp = (const int8_t *)wprep; a.out_mul = out_mul; a.bias = bias; a.post_scale = post_scale;
     a.post_shift = post_shift; a.residual = residual; a.nbr = nbr; a.count_out = count_out;
     a.feats_out = feats_out; a.absmax_out = absmax_out; a.cap_out = cap_out; a.kvol = kvol;
     a.relu = (flags & AQ3D_FLAG_RELU) ? 1 : 0;
@@ -691,21 +657,20 @@ extern "C" int aq3d_spconv_coded(const int8_t *codes, int32_t cap_in, const void
     AQ3D_REQUIRE(!(flags & AQ3D_FLAG_SKIP_F32) || next_codes, "aq3d_spconv_coded: AQ3D_FLAG_SKIP_F32 without next_codes would discard the output");
     a.next_scale = next_scale; a.next_codes = next_codes; a.next_qmax = next_codes ? (float)((1 << (next_bits - 1)) - 1) : 0.f;
     a.skip_f32 = (flags & AQ3D_FLAG_SKIP_F32) ? 1 : 0;
-    // Cout = 128: two 64-column blocks per row tile (measured on W150k, 35 k rows: 71 us against 98 us for one 128-column workgroup
-    // and 66 us for four 32-column ones, which lose whole-frame throughput to the 4x repeated gathers: 599 against 614 frames/s)
+    // Cout = 128: two 64-column blocks per row tile (round 2, fp16 pipe, W150k, 35 k rows: 71 us against 98 us for one 128-column
+    // workgroup and 66 us for four 32-column ones, which lose whole-frame throughput to the 4x repeated gathers)
 #define AQ3D_CODED_DISPATCH(PL_) \
     do { \
-        if (cin == 16 && cout == 16) return launch_cd<16, 27, 4, PL_>(a, stream); \
-        if (cin == 16 && cout == 32) return launch_cd<32, 27, 8, PL_>(a, stream);    /* 58 KB of W' per workgroup: 8 waves share it */ \
-        /* (32 -> 32 with the whole W' resident like Cin = 16 — 110 KB, one workgroup per CU — measured 41 us against 30 us) */ \
+        if (cin == 16 && cout == 16) return launch_cd<16, 4, PL_>(a, stream); \
+        if (cin == 16 && cout == 32) return launch_cd<32, 8, PL_>(a, stream); \
         if (cin == 32 && cout == 32) return launch_cw<32, 32, 32, PL_>(a, stream); \
         if (cin == 32 && cout == 64) return launch_cw<32, 64, 64, PL_>(a, stream); \
         if (cin == 64 && cout == 64) return launch_cw<64, 64, 64, PL_>(a, stream); \
         if (cin == 64 && cout == 128) return launch_cw<64, 128, 64, PL_>(a, stream); \
         if (cin == 128 && cout == 128) return launch_cw<128, 128, 64, PL_>(a, stream); \
     } while (0)
-    if (flags & AQ3D_FLAG_W_FP16) AQ3D_CODED_DISPATCH(1);
-    AQ3D_CODED_DISPATCH(2);
+    if (flags & AQ3D_FLAG_W16) AQ3D_CODED_DISPATCH(2);      // planes d2 d1 only (the kernels lift their sums by 256)
+    AQ3D_CODED_DISPATCH(3);
 #undef AQ3D_CODED_DISPATCH
     return AQ3D_ERR_UNSUPPORTED;
 }

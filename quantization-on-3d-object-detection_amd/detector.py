@@ -48,11 +48,11 @@ class Detector3DTemplate(nn.Module):
         self.level_capacity_factor = 4.0
         self.level_capacity = None
         self.voxelize_on_device = True   # False: consume batch_dict['voxels'/'voxel_coords'] when present
-        # quantised sparse convs: False = weights as an fp16 hi|lo pair (two MFMAs per product, fp32-grade sums, every layer within
-        # 2e-5 of the oracle); True = ONE fp16 weight per product (the north star's "int8 weights x fp16 activations" precision:
-        # ~2^-12 per weight, layers within 1e-3 of their output scale, half the matrix work). Set before the first forward
-        # (or call invalidate_engine()).
-        self.sparse_fp16_weights = False
+        # quantised sparse convs (int8 codes x fixed-point weight planes on the int8 matrix pipe): False = 24-bit weights (three int8
+        # planes, fp32-grade sums, every layer within 2e-5 of the oracle); True = 16-bit weights (two planes: <= 2^-9 per weight on a
+        # +-127 scale, layers within 1e-3 of their output scale — measured ~5e-5 —, two thirds of the matrix work). Set before the
+        # first forward (or call invalidate_engine()).
+        self.sparse_w16 = False
 
     @property
     def mode(self):

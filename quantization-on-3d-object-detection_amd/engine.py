@@ -142,7 +142,7 @@ class Engine:
         self.arena = _Arena(device)
         self.steps = []
         self.tensors = {}
-        self.sparse_fp16_weights = bool(getattr(det, "sparse_fp16_weights", False))
+        self.sparse_w16 = bool(getattr(det, "sparse_w16", False))
         self._head_args = {}
         self._force_rows = False     # teacher-forced tests: run the rows-only quantiser even where a producer epilogue does it
         if isinstance(det.backbone_3d, VoxelResBackBone8xVoxelNeXt):
@@ -267,8 +267,9 @@ class Engine:
             rec["coded"] = rec["quant"]["use_codes"] = coded
             if coded:
                 rec["codes"] = torch.zeros((cap, cin), dtype=torch.int8, device=dev)
-                # W' = code * (d_c / S) as fp16 hi | lo planes + epilogue multipliers S * t_o, rebuilt per frame by aq3d_spconv_prep
-                rec["wprep"] = torch.zeros((kvol, cout, 2, cin), dtype=torch.float16, device=dev)
+                # W'' = rint(code * (d_c / S) * 2^16) as three int8 planes + epilogue multipliers S * t_o / 2^16, rebuilt per frame by
+                # aq3d_spconv_prep
+                rec["wprep"] = torch.zeros((kvol, cout, 3, cin), dtype=torch.int8, device=dev)
                 rec["out_mul"] = torch.zeros((cout,), dtype=f32, device=dev)
             else:
                 rec["fq"] = torch.zeros((cap, cin), dtype=f32, device=dev)
@@ -981,7 +982,7 @@ class Engine:
                                      absmax_out=self.arena.view(out["amax"]), out=out["buf"],
                                      next_scale=None if nx is None else nx["scale"], next_codes=None if nx is None else nx["codes"],
                                      next_bits=8 if nx is None else nx["bits"], skip_f32=bool(rec.get("skip_f32")),
-                                     fp16_weights=self.sparse_fp16_weights)
+                                     w16=self.sparse_w16)
                 return
             L = ops._lib.load()
             with _Timed(self, "quantize_rows"):

@@ -250,7 +250,7 @@ def quantize_rows(x, amax, count, bits=8, per_tensor=False, want_codes=True, wan
 
 ACT_F32, ACT_I8 = 0, 1
 W_F32, W_I8 = 0, 1
-FLAG_RELU, FLAG_SKIP_F32, FLAG_W_FP16 = 1, 2, 4
+FLAG_RELU, FLAG_SKIP_F32, FLAG_W16 = 1, 2, 4
 
 
 def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequant=None, bias=None, post_scale=None,
@@ -277,14 +277,14 @@ def spconv_coded_supported(cin, cout, kvol):
 
 def spconv_prep(x, amax, count, weight_codes, w_dequant, bits=8, per_tensor=False, out=None, cap=None):
     """Quantiser + per-frame weight copy of one QConvNd layer in ONE launch (aq3d_spconv_prep).
-    x f32 [cap, C]; weight_codes i8 [kvol, cout, C] → (codes i8 [cap, C], wprep f16 [kvol, cout, 2, C], out_mul f32 [cout]).
+    x f32 [cap, C]; weight_codes i8 [kvol, cout, C] → (codes i8 [cap, C], wprep i8 [kvol, cout, 3, C] (weight planes), out_mul f32 [cout]).
     x=None: weight copy only (static PTQ, once); weight_codes=None: rows only."""
     L = _lib.load()
     if out is None:
         cap_, C = x.shape
         kvol, cout, _ = weight_codes.shape
         codes = torch.zeros((cap_, C), dtype=torch.int8, device=x.device)
-        wprep = torch.empty((kvol, cout, 2, C), dtype=torch.float16, device=x.device)
+        wprep = torch.empty((kvol, cout, 3, C), dtype=torch.int8, device=x.device)
         out_mul = torch.empty((cout,), dtype=f32, device=x.device)
     else:
         codes, wprep, out_mul = out
@@ -303,17 +303,18 @@ def spconv_prep(x, amax, count, weight_codes, w_dequant, bits=8, per_tensor=Fals
 
 def spconv_coded(codes, wprep, out_mul, nbr, count_out, *, bias=None, post_scale=None, post_shift=None,
                  residual=None, relu=False, absmax_out=None, out=None, next_scale=None, next_codes=None, next_bits=8, skip_f32=False,
-                 fp16_weights=False):
-    """Gather-GEMM on int8-coded activations (aq3d_spconv_coded). codes i8 [cap_in, cin]; wprep f16 [kvol, cout, 2, cin]."""
+                 w16=False):
+    """Gather-GEMM on int8-coded activations (aq3d_spconv_coded). codes i8 [cap_in, cin]; wprep i8 [kvol, cout, 3, cin];
+    w16: multiply the two upper weight planes only (16-bit fixed-point weights)."""
     L = _lib.load()
     cap_out, kvol = nbr.shape
     cap_in, cin = codes.shape
     cout = wprep.shape[1]
-    assert tuple(wprep.shape) == (kvol, cout, 2, cin), (tuple(wprep.shape), (kvol, cout, 2, cin))
+    assert tuple(wprep.shape) == (kvol, cout, 3, cin) and wprep.dtype == torch.int8, (tuple(wprep.shape), (kvol, cout, 3, cin))
     y = out if out is not None else torch.empty((cap_out, cout), dtype=f32, device=nbr.device)
     check(L.aq3d_spconv_coded(_p(codes), cap_in, _p(wprep), _p(out_mul), _p(bias), _p(post_scale), _p(post_shift), _p(residual),
                               _p(nbr), _p(count_out), cap_out, cin, cout, kvol,
-                              (FLAG_RELU if relu else 0) | (FLAG_SKIP_F32 if skip_f32 else 0) | (FLAG_W_FP16 if fp16_weights else 0), _p(y),
+                              (FLAG_RELU if relu else 0) | (FLAG_SKIP_F32 if skip_f32 else 0) | (FLAG_W16 if w16 else 0), _p(y),
                               _p(absmax_out),
                               _p(next_scale), _p(next_codes), int(next_bits), _stream()), "aq3d_spconv_coded")
     return y

@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--voxels", type=int, default=35000)
     ap.add_argument("--channels", type=int, nargs="+", default=[32, 64, 128])
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--w16", action="store_true")
     ap.add_argument("--dense", action="store_true", help="conv2d_i8_kernel on the benchmark's BEV layers instead of spconv_cw_kernel")
     args = ap.parse_args()
     path = build_stamped()
@@ -98,10 +99,10 @@ def main():
     shape = [41, 1504, 1504]
     idx = SL.occupancy("sheet", args.voxels)
     m = len(idx)
-    coords = torch.from_numpy(idx).to(dev)
     count = torch.tensor([m], dtype=torch.int32, device=dev)
-    table = ops.hash_build(coords, count, shape)
-    nbr = ops.subm_neighbors(coords, count, shape, (3, 3, 3), table)
+    lv = ops.IndexLevel(shape, 1, m, dev)
+    ops.level_from_coords(torch.from_numpy(idx).to(dev), lv)
+    nbr = ops.subm_neighbors(lv)
     raw = ctypes.CDLL(path)
     for C in args.channels:
         g = torch.Generator().manual_seed(C)
@@ -112,22 +113,22 @@ def main():
         codes, wprep, out_mul = ops.spconv_prep(x, amax, count, wq, wdq, bits=8, per_tensor=False)
         ct = 64 if C >= 64 else 32
         grid = (m + 127) // 128 * (C // ct) + 8 * (C // ct)
-        stamps = torch.zeros((grid + 16, 4, 8), dtype=torch.int64, device=dev)
+        stamps = torch.zeros((2 * grid + 64, 8, 8), dtype=torch.int64, device=dev)
         assert raw.aq3d_diag_set_stamps(ctypes.c_void_p(stamps.data_ptr())) == 0
         for _ in range(3):
-            ops.spconv_coded(codes, wprep, out_mul, nbr, count)
+            ops.spconv_coded(codes, wprep, out_mul, nbr, count, w16=args.w16)
         torch.cuda.synchronize()
         stamps.zero_()
         t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0.record()
-        ops.spconv_coded(codes, wprep, out_mul, nbr, count)
+        ops.spconv_coded(codes, wprep, out_mul, nbr, count, w16=args.w16)
         t1.record()
         torch.cuda.synchronize()
         s = stamps.cpu().numpy().reshape(-1, 8)
         s = s[s[:, 7] != 0]
         units = (s[:, 7] >> 48).astype(np.float64)
         total = (s[:, 7] & ((1 << 48) - 1)).astype(np.float64)
-        names = ["prologue", "fill", "A wait + convert", "MFMA loop", "W' store", "barrier", "epilogue"]
+        names = ["prologue", "fill", "next unit + W load issue", "MFMA loop", "W store", "barrier", "epilogue"]
         print("C = %d, %d rows, %d live waves, kernel %.1f us (with stamps); stamp clock ticks per wave, mean (share of the wave's total):"
               % (C, m, len(s), t0.elapsed_time(t1) * 1e3))
         for i, nme in enumerate(names):

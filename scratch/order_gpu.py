@@ -21,7 +21,7 @@ for k, s, p in [((3, 3, 3), (2, 2, 2), (1, 1, 1)), ((3, 3, 3), (2, 2, 2), (1, 1,
     idx, nbr, osh = OS.conv_outputs(levels[-1][0], levels[-1][1], k, s, p)
     levels.append((idx, [int(v) for v in osh]))
 dev = torch.device("cuda:0")
-fp16w = "--fp16w" in sys.argv
+fp16w = "--w16" in sys.argv
 
 
 def class_key(idx, sh):
@@ -54,7 +54,7 @@ for (idx, sh), C in zip(levels, (16, 32, 64, 128)):
     pc = (OS.subm_neighbors(idx, sh) >= 0).sum(1)
     orders = {"random": rng.permutation(M), "class7": raster[np.argsort(ck[raster], kind="stable")],
               "class7 heavy-first": raster[np.argsort(-ck[raster], kind="stable")],
-              "class7 by class weight desc": None, "popcount desc": raster[np.argsort(-pc[raster], kind="stable")]}
+              "class7 by class weight desc": None, "popcount desc": raster[np.argsort(-pc[raster], kind="stable")], "device": None}
     # classes ordered by their mean neighbour count, heaviest first
     cls = np.unique(ck)
     wgt = {c_: pc[ck == c_].mean() for c_ in cls}
@@ -62,10 +62,16 @@ for (idx, sh), C in zip(levels, (16, 32, 64, 128)):
     rk = np.array([rank[v] for v in ck])
     orders["class7 by class weight desc"] = raster[np.argsort(rk[raster], kind="stable")]
     for name, o in orders.items():
-        coords = torch.from_numpy(np.ascontiguousarray(idx[o])).to(dev)
+        if name != "device" and o is None:
+            continue
         count = torch.tensor([M], dtype=torch.int32, device=dev)
-        table = ops.hash_build(coords, count, sh)
-        nbr = ops.subm_neighbors(coords, count, sh, (3, 3, 3), table)
+        if name == "device":       # the index builder's own row order
+            lv = ops.IndexLevel(sh, 1, M, dev)
+            ops.level_from_coords(torch.from_numpy(np.ascontiguousarray(idx)).to(dev), lv)
+            nbr = ops.subm_neighbors(lv)
+        else:
+            ref = OS.subm_neighbors(idx[o], sh)
+            nbr = torch.from_numpy(ref).to(dev)
         g = torch.Generator().manual_seed(C)
         x = torch.relu(torch.randn(M, C, generator=g)).to(dev)
         w = torch.randn(C, 3, 3, 3, C, generator=g) / np.sqrt(13 * C)
@@ -76,9 +82,9 @@ for (idx, sh), C in zip(levels, (16, 32, 64, 128)):
         amax = ops.absmax_cols(x, count)
         out = torch.empty((M, C), device=dev)
         am_out = torch.zeros(C, device=dev)
-        bufs = (torch.zeros((M, C), dtype=torch.int8, device=dev), torch.empty((27, C, 2, C), dtype=torch.float16, device=dev), torch.empty((C,), device=dev))
+        bufs = (torch.zeros((M, C), dtype=torch.int8, device=dev), torch.empty((27, C, 3, C), dtype=torch.int8, device=dev), torch.empty((C,), device=dev))
         ops.spconv_prep(x, amax, count, wk8, wdq, out=bufs)
-        us = timed(lambda: ops.spconv_coded(bufs[0], bufs[1], bufs[2], nbr, count, post_scale=ps, post_shift=pt, relu=True, absmax_out=am_out, out=out, fp16_weights=fp16w))
+        us = timed(lambda: ops.spconv_coded(bufs[0], bufs[1], bufs[2], nbr, count, post_scale=ps, post_shift=pt, relu=True, absmax_out=am_out, out=out, w16=fp16w))
         nb = nbr.cpu().numpy() >= 0
         pad = (-M) % 128
         live = np.concatenate([nb, np.zeros((pad, 27), bool)]).reshape(-1, 128, 27).any(1).mean()

@@ -122,11 +122,11 @@ def test_w150k_int8_teacher_forced(dev, w150k):
     assert len(res_s) == 21 and len(res_d) == len(eng.dense_convs) >= 12 + 2 + 1 + 2 * 5
     _assert_layers(res_s)
     _assert_layers(res_d)
-    # the single-fp16-weight mode of the sparse convs (AQ3D_FLAG_W_FP16, detector.sparse_fp16_weights): same layers, bar 1e-3
-    eng.sparse_fp16_weights = True
+    # the 16-bit-weight mode of the sparse convs (AQ3D_FLAG_W16, detector.sparse_w16): same layers, bar 1e-3
+    eng.sparse_w16 = True
     res_h = teacher.sparse_layers(eng, maps, lambda n: trace["vfe"][0] if n == "vfe" else trace[n])
-    eng.sparse_fp16_weights = False
-    teacher.report("W150k SmoothQuant w8a8, teacher-forced sparse layers, ONE fp16 weight per product", res_h)
+    eng.sparse_w16 = False
+    teacher.report("W150k SmoothQuant w8a8, teacher-forced sparse layers, 16-bit fixed-point weights", res_h)
     _assert_layers(res_h, 1e-3)
     # (iv) boxes from the oracle's BEV features
     bev = trace["spatial_features_2d"][0].permute(1, 2, 0).numpy()

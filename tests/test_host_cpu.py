@@ -406,3 +406,28 @@ def test_bench_frames_fit_the_bench_capacities():
     caps = [cap0] + [int(np.ceil(factor * cap0))] * 4
     assert all(w <= c for w, c in zip(worst, caps)), (worst, caps)
     assert worst[1] > 65536
+
+
+def test_library_holds_no_packed_fp32_instructions(tmp_path):
+    """Canary of the round-2 NMS fix (DESIGN.md §9.1, build.py::NO_PACKED_FP32): the rotated-overlap geometry as the compiler lowers
+    it with packed-fp32 instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) was not reproducible next to other streams'
+    kernels on this stack. The library is built without them; a toolchain update or an edit of the flags that brings them back
+    must fail HERE, not as one deviating frame in six thousand."""
+    import shutil
+    import subprocess
+    from amdq3d import lib
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.isfile(objdump) or not os.path.isfile(lib.LIB_PATH):
+        pytest.skip("needs the ROCm llvm-objdump and a built libaq3d.so")
+    so = tmp_path / "libaq3d.so"
+    shutil.copy(lib.LIB_PATH, so)
+    subprocess.run([objdump, "--offloading", str(so)], check=True, capture_output=True, cwd=tmp_path)
+    objs = [p for p in tmp_path.iterdir() if "gfx950" in p.name]
+    assert objs, "no gfx950 code object found in libaq3d.so"
+    n_inst, bad = 0, []
+    for o in objs:
+        asm = subprocess.run([objdump, "-d", str(o)], check=True, capture_output=True, text=True).stdout
+        n_inst += asm.count("\n")
+        bad += [l.strip() for l in asm.splitlines() if re.search(r"\bv_pk_(add|mul|fma)_f32\b", l)]
+    assert n_inst > 10000, "the disassembly looks empty"
+    assert not bad, "packed-fp32 instructions in libaq3d.so (build.py::NO_PACKED_FP32 lost?): %s" % bad[:5]

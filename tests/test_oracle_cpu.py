@@ -208,3 +208,138 @@ def test_voxelnext_bev_out_and_decode_follow_the_reference_torch_ops():
     np.testing.assert_allclose(b[:, 0], xs[keep], rtol=0, atol=4e-6)     # my test line multiplies in another order
     np.testing.assert_allclose(b[:, 6], np.arctan2(rot[rows, 1], rot[rows, 0])[keep], rtol=0, atol=1e-6)
     assert b.shape[1] == 9
+
+
+# ------------------------------------------------------------------ independent cross-checks of the UNPINNED oracle parts
+@pytest.mark.parametrize("bits", [8, 4])
+def test_fake_quant_equals_torch_fake_quantize(bits):
+    """oracle.quantizer.fake_quant restates pytorch_quantization's TensorQuantizer (library absent). torch's own fake-quantise ops
+    implement the same published formula — q = clamp(round_half_even(x / s), qmin, qmax) * s with s = amax / qmax, zero point 0 —
+    and are an INDEPENDENT implementation: codes must agree exactly (ties included), values to the last fp32 rounding of q * s vs q / (1/s)."""
+    import torch
+    from oracle import quantizer as Q
+    rng = np.random.default_rng(bits)
+    qmax = 2 ** (bits - 1) - 1
+    x = rng.normal(0, 1, (257, 24)).astype(np.float32) * rng.uniform(0.01, 30, 24).astype(np.float32)
+    # exact ties of the rounding, values beyond amax (static clipping), zeros
+    amax_t = np.float32(1.984375)                       # amax / qmax exact in fp32 for 8 bits
+    step = amax_t / np.float32(qmax)
+    ties = (np.arange(-qmax - 3, qmax + 3, dtype=np.float32) + np.float32(0.5)) * step
+    x[:len(ties), 0] = ties[:257][:len(x)] if len(ties) <= len(x) else ties[:len(x)]
+    x[0, 1] = 0.0
+    # per tensor, calibrated amax (clipping exercised)
+    out, codes, div = Q.fake_quant(x, amax_t, bits, return_codes=True)
+    ref = torch.fake_quantize_per_tensor_affine(torch.from_numpy(x), float(step), 0, -qmax - 1, qmax).numpy()
+    ref_codes = np.clip(np.rint(x.astype(np.float64) / float(step)), -qmax - 1, qmax)
+    agree = codes == ref_codes
+    # x * (qmax / amax) and x / (amax / qmax) are both fp32 roundings of the same real quotient: they can differ only when the
+    # quotient lies within an ulp of a tie; everywhere else the codes are identical
+    near_tie = np.abs((x.astype(np.float64) / float(step)) % 1.0 - 0.5) < 1e-4
+    assert np.all(agree | near_tie) and agree.mean() > 0.99
+    np.testing.assert_allclose(out[agree], ref[agree], rtol=3e-7, atol=0)
+    # per channel (axis 1), dynamic amax
+    amax = Q.reduce_amax(x, axis=1)
+    out_c, codes_c, _ = Q.fake_quant(x, amax, bits, return_codes=True)
+    scale = (amax.reshape(-1) / np.float32(qmax)).astype(np.float32)
+    ref_c = torch.fake_quantize_per_channel_affine(torch.from_numpy(x), torch.from_numpy(scale), torch.zeros(24, dtype=torch.int32), 1,
+                                                   -qmax - 1, qmax).numpy()
+    ref_codes_c = np.clip(np.rint(x.astype(np.float64) / scale.astype(np.float64)[None, :]), -qmax - 1, qmax)
+    agree_c = codes_c == ref_codes_c
+    near_c = np.abs((x.astype(np.float64) / scale.astype(np.float64)[None, :]) % 1.0 - 0.5) < 1e-4
+    assert np.all(agree_c | near_c) and agree_c.mean() > 0.995
+    np.testing.assert_allclose(out_c[agree_c], ref_c[agree_c], rtol=3e-7, atol=0)
+    # a dead channel: amax <= 2^-24 quantises to zeros instead of dividing by zero
+    z = np.zeros((5, 3), np.float32)
+    assert np.array_equal(Q.fake_quant(z, Q.reduce_amax(z, axis=1), bits), z)
+
+
+def _clip_area64(pa, pb):
+    """Area of the intersection of two convex polygons (float64 Sutherland-Hodgman) — independent of iou3d_nms.c's
+    intersection-point + angular-sort construction."""
+    def inside(p, a, b):
+        return (b[0] - a[0]) * (p[1] - a[1]) - (b[1] - a[1]) * (p[0] - a[0]) >= 0
+    def inter(p, q, a, b):
+        d1, d2 = q - p, b - a
+        t = ((a[0] - p[0]) * d2[1] - (a[1] - p[1]) * d2[0]) / (d1[0] * d2[1] - d1[1] * d2[0])
+        return p + t * d1
+    out = [np.asarray(v, np.float64) for v in pa]
+    for i in range(len(pb)):
+        a, b = np.asarray(pb[i], np.float64), np.asarray(pb[(i + 1) % len(pb)], np.float64)
+        src, out = out, []
+        if not src:
+            break
+        for j in range(len(src)):
+            p, q = src[j], src[(j + 1) % len(src)]
+            if inside(q, a, b):
+                if not inside(p, a, b):
+                    out.append(inter(p, q, a, b))
+                out.append(q)
+            elif inside(p, a, b):
+                out.append(inter(p, q, a, b))
+    if len(out) < 3:
+        return 0.0
+    v = np.asarray(out)
+    return 0.5 * abs(float(np.dot(v[:, 0], np.roll(v[:, 1], -1)) - np.dot(v[:, 1], np.roll(v[:, 0], -1))))
+
+
+def _corners64(box):
+    x, y, dx, dy, th = (float(box[i]) for i in (0, 1, 3, 4, 6))
+    c, s = np.cos(th), np.sin(th)
+    loc = np.array([[dx / 2, dy / 2], [-dx / 2, dy / 2], [-dx / 2, -dy / 2], [dx / 2, -dy / 2]])      # counter-clockwise
+    return loc @ np.array([[c, s], [-s, c]]) + np.array([x, y])
+
+
+def test_rotated_overlap_equals_float64_polygon_clipping():
+    """oracle/iou3d_nms.c restates the geometry of pcdet/ops/iou3d_nms/src/iou3d_cpu.cpp:128-229 (fp32, intersection points +
+    corner-in-box tests + angular sort). Sutherland-Hodgman clipping in float64 is a different algorithm for the same area:
+    1000 random pairs + degenerate ones (identical, touching, contained, axis-aligned, tiny, needle-shaped). The reference counts
+    a corner as inside the other box up to MARGIN = 1 cm outside it (iou3d_cpu.cpp:77-84), which can only ADD slivers: pairs with
+    no corner inside that band must agree within 2e-4 of the smaller box's area (fp32 rounding, EPS = 1e-8 tolerances), the
+    others may exceed the exact area by at most MARGIN x the mean perimeter and never fall below it."""
+    from oracle import decode as OD
+    rng = np.random.default_rng(7)
+    n = 1000
+    a = np.zeros((n, 7), np.float32)
+    b = np.zeros((n, 7), np.float32)
+    for arr in (a, b):
+        arr[:, 0:2] = rng.uniform(-3, 3, (n, 2))
+        arr[:, 3:5] = rng.uniform(0.3, 6, (n, 2))
+        arr[:, 5] = 1.5
+        arr[:, 6] = rng.uniform(-np.pi, np.pi, n)
+    special = np.array([[0, 0, 0, 4, 2, 1.5, 0.3], [0, 0, 0, 4, 2, 1.5, 0.3],          # identical
+                        [0, 0, 0, 4, 2, 1.5, 0.0], [4, 0, 0, 4, 2, 1.5, 0.0],            # touching edges
+                        [0, 0, 0, 6, 6, 1.5, 0.2], [0.1, 0.2, 0, 1, 1, 1.5, 1.1],        # contained
+                        [0, 0, 0, 4, 2, 1.5, 0.0], [1, 0.5, 0, 4, 2, 1.5, np.pi / 2],    # axis-aligned, rotated by 90 degrees
+                        [0, 0, 0, 0.05, 0.05, 1.5, 0.7], [0.01, 0, 0, 0.05, 0.05, 1.5, 0.1],   # tiny
+                        [0, 0, 0, 40, 0.1, 1.5, 0.5], [0, 0, 0, 40, 0.1, 1.5, -0.5],     # needles crossing
+                        [10, 10, 0, 1, 1, 1.5, 0], [-10, -10, 0, 1, 1, 1.5, 0]], np.float32)  # disjoint
+    a = np.concatenate([a, special[0::2]])
+    b = np.concatenate([b, special[1::2]])
+    def corner_in_band(box, other, margin=1e-2):
+        """some corner of `box` lies within +-margin of `other`'s boundary (where MARGIN changes the inside test)"""
+        c, s_ = np.cos(-float(other[6])), np.sin(-float(other[6]))
+        for p in _corners64(box):
+            d = p - np.array([float(other[0]), float(other[1])])
+            rx, ry = d[0] * c - d[1] * s_, d[0] * s_ + d[1] * c
+            inside_m = abs(rx) < other[3] / 2 + margin and abs(ry) < other[4] / 2 + margin
+            inside_0 = abs(rx) < other[3] / 2 - margin and abs(ry) < other[4] / 2 - margin
+            if inside_m != inside_0:
+                return True
+        return False
+
+    L = OD._lib()
+    worst, tight = 0.0, 0
+    for i in range(len(a)):
+        ov = np.zeros((1, 1), np.float32)
+        L.oracle_overlap_bev_matrix(OD._fptr(np.ascontiguousarray(a[i:i + 1])), 1, 7, OD._fptr(np.ascontiguousarray(b[i:i + 1])), 1, 7, OD._fptr(ov))
+        ref = _clip_area64(_corners64(a[i]), _corners64(b[i]))
+        small = min(float(a[i, 3] * a[i, 4]), float(b[i, 3] * b[i, 4]))
+        err = float(ov[0, 0]) - ref
+        if corner_in_band(a[i], b[i]) or corner_in_band(b[i], a[i]):
+            perim = float(a[i, 3] + a[i, 4] + b[i, 3] + b[i, 4])
+            assert -max(2e-4 * small, 1e-4) <= err <= 1e-2 * perim + 1e-4, (i, a[i], b[i], float(ov[0, 0]), ref)
+        else:
+            tight += 1
+            assert abs(err) <= max(2e-4 * small, 1e-4), (i, a[i], b[i], float(ov[0, 0]), ref)
+            worst = max(worst, abs(err) / max(small, 1e-9))
+    assert tight >= 0.8 * len(a) and worst <= 2e-3
