@@ -29,7 +29,8 @@ def build_model(cfg, n_points, n_voxels, n_frames=2, seed=4):
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
     init_synthetic_weights(model, seed)
     model.eval()
-    return ds, model
+    model.sparse_w16 = False          # tests hold the layers to the 2e-5 bar: 24-bit weight planes (the product default is 16-bit,
+    return ds, model                  # covered by its own tests at its own bar)
 
 
 def match_boxes(boxes_a, scores_a, labels_a, boxes_b, scores_b, labels_b, iou_tol=1e-3, score_tol=1e-3, z_tol=1e-3):

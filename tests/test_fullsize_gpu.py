@@ -127,7 +127,7 @@ def test_w150k_int8_teacher_forced(dev, w150k):
     res_h = teacher.sparse_layers(eng, maps, lambda n: trace["vfe"][0] if n == "vfe" else trace[n])
     eng.sparse_w16 = False
     teacher.report("W150k SmoothQuant w8a8, teacher-forced sparse layers, 16-bit fixed-point weights", res_h)
-    _assert_layers(res_h, 1e-3)
+    _assert_layers(res_h, 3e-4)         # contract 1e-3 (north-star tolerance); measured <= 1e-4
     # (iv) boxes from the oracle's BEV features
     bev = trace["spatial_features_2d"][0].permute(1, 2, 0).numpy()
     B = eng.run_head_from(torch.from_numpy(np.ascontiguousarray(bev))[None].to(dev))
