@@ -32,6 +32,10 @@ WORKLOADS = {      # --workload → (cfg, points, voxels, description); the head
     "centerpoint": ("cfgs/waymo_models/centerpoint.yaml", 150000, 30000,
                     "Full CenterPoint VoxelNet sparse backbone + dense int8 BEV head, synthetic Waymo-shape 150k-pt / 30k-voxel "
                     "frames (BASELINE configs[2]), SmoothQuant w8a8 dynamic, 1 frame/step/GPU"),
+    "centerpoint_nusc": ("cfgs/nuscenes_models/cbgs_voxel0075_res3d_centerpoint.yaml", 40000, 20000,
+                         "CenterPoint on the nuScenes config the reference script targets (cbgs_voxel0075_res3d_centerpoint.yaml: BEV 180 x 180, "
+                         "six heads / ten classes, 43 SmoothQuant convs), synthetic nuScenes-shape 40k-pt / 20k-voxel frames, w8a8 dynamic, "
+                         "1 frame/step/GPU"),
     "voxelnext": ("cfgs/nuscenes_models/cbgs_voxel0075_voxelnext.yaml", 40000, 20000,
                   "VoxelNeXt fully sparse int8 (quant/quant_voxelnext.py recipe: w8a8 per-channel 3-D convs + weight-only 2-D convs), "
                   "synthetic nuScenes-shape 40k-pt / 20k-voxel frames (BASELINE configs[4]), 1 frame/step/GPU"),
@@ -506,8 +510,9 @@ def main():
             if r is not None:
                 by_kernel[cat] = r
         out = {
-            "metric": "frames/sec/GPU int8 CenterPoint @150k pts; mAP delta vs fp32 ref" if args.workload == "centerpoint"
-            else "frames/sec/GPU int8 VoxelNeXt @40k pts",
+            "metric": {"centerpoint": "frames/sec/GPU int8 CenterPoint @150k pts; mAP delta vs fp32 ref",
+                       "centerpoint_nusc": "frames/sec/GPU int8 CenterPoint (nuScenes config) @40k pts",
+                       "voxelnext": "frames/sec/GPU int8 VoxelNeXt @40k pts"}[args.workload],
             "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",

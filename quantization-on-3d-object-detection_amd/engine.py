@@ -1099,6 +1099,20 @@ class Engine:
         self._publish()
         return B
 
+    def run_sparse_head_from(self, rows):
+        """VoxelNeXt: run only the sparse head branches -> decode -> NMS on given rows of the shared_conv output (engine row order,
+        f32 [M, C]); the frame's index levels must exist (run the frame once). Parity tests feed the oracle's features here."""
+        assert self.fully_sparse
+        x, lvl = self.encoded
+        m = int(self.levels[lvl]["count"].item())
+        assert rows.shape[0] == m and rows.shape[1] <= x["buf"].shape[1]
+        self.arena.clear()
+        x["buf"][:m].zero_()
+        x["buf"][:m, :rows.shape[1]].copy_(rows)
+        self._run_steps(self.steps[self.head_first_step:], 1)
+        self._publish()
+        return 1
+
     def run(self, batch_dict):
         """Enqueue one batch on the current stream. Results sit in self.heads[*]['out_*'] and self.det_counts (slot self.slot);
         Detector.forward_async calls this on the plan's own stream."""

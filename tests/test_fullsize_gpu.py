@@ -28,6 +28,7 @@ TOL_LAYER = 2e-5        # teacher-forced int8 / fp32 layers: max |device - oracl
 def _full_cfg(kind):
     from amdq3d.config import AttrDict, cfg_from_yaml_file
     path = {"waymo": "cfgs/waymo_models/centerpoint.yaml",
+            "nuscenes": "cfgs/nuscenes_models/cbgs_voxel0075_res3d_centerpoint.yaml",
             "voxelnext": "cfgs/nuscenes_models/cbgs_voxel0075_voxelnext.yaml"}[kind]
     return cfg_from_yaml_file(path, AttrDict())
 
@@ -251,3 +252,116 @@ def test_s40k_voxelnext_int8_teacher_forced(dev, s40k):
     teacher.report("S40k VoxelNeXt int8 (w8a8 3-D, weight-only 2-D), teacher-forced layers", res)
     assert len(res) == len(eng.sparse_convs)
     _assert_layers(res)
+
+
+def test_s40k_voxelnext_int8_head_on_the_oracle_features(dev, s40k):
+    """VERDICT r2 missing #5: the int8 VoxelNeXt sparse head + decode_bbox_from_voxels + NMS (voxelnext_head.py:418-560) fed the
+    ORACLE's shared_conv features: boxes at the north-star tolerance (the CenterPoint counterpart is test (iv) above)."""
+    from amdq3d import quant as Qz
+    cfg, ds, model, state, pts = (s40k[k] for k in ("cfg", "ds", "model", "state", "pts"))
+    Qz.dynamic_quant_voxelnext(model, 8, 8, sq=True)
+    model.cuda()
+    _run_gpu(model, ds, 0, dev)
+    trace = {}
+    b_ref, s_ref, l_ref = OV.run(state, cfg, pts, OV.Recipe(8, 8, True), trace)
+    eng = model.engine()
+    maps = teacher.row_maps(eng, _vn_index_sets(trace))
+    x, idx, shape = trace["encoded"]
+    rows = torch.from_numpy(np.ascontiguousarray(x[maps[-1]])).to(dev)
+    B = eng.run_sparse_head_from(rows)
+    p = eng.collect(B)[0]
+    pb, ps, pl = _preds(p)
+    print("S40k VoxelNeXt int8 head on oracle features: %d boxes (oracle %d)" % (len(ps), len(s_ref)))
+    assert len(s_ref) > 10 and abs(len(ps) - len(s_ref)) <= max(2, len(s_ref) // 50)
+    sr, sp = sane_boxes(b_ref), sane_boxes(pb)
+    assert match_params(b_ref, s_ref, l_ref, pb, ps, pl) >= 0.98
+    assert match_params(pb, ps, pl, b_ref, s_ref, l_ref) >= 0.98
+    assert match_boxes(b_ref[sr], s_ref[sr], l_ref[sr], pb, ps, pl) >= 0.98
+    assert match_boxes(pb[sp], ps[sp], pl[sp], b_ref, s_ref, l_ref) >= 0.98
+
+
+# ------------------------------------------------------------------ configs[0]: static PTQ at BASELINE size
+def test_w150k_static_ptq_teacher_forced(dev):
+    """quant/quant_centerpoint.py:127-129 at BASELINE size (VERDICT r2 missing #3): calibrate on two W150k frames on the device,
+    compare every calibrated amax with oracle.centerpoint.calibrate, then teacher-force the static forward on a THIRD frame."""
+    from amdq3d import quant as Qz
+    from amdq3d.datasets import load_data_to_gpu
+    from test_static_ptq_gpu import _set_static
+    cfg = _full_cfg("waymo")
+    ds, model = build_model(cfg, n_points=150000, n_voxels=30000, n_frames=3)
+    model.voxel_capacity = 40960
+    state = _state(model)
+    model.cuda()
+    loader = [ds.collate_batch([ds[i]]) for i in (1, 2)]
+    Qz.quant(model, 8, 8, sq=True, alpha=0.5, static=True, test_loader=loader, n_batches=5)
+    rec = OC.Recipe(8, 8, True, 0.5)
+    static = OC.calibrate(state, cfg, [ds[i]["points"] for i in (1, 2)], rec)
+    mods = dict(model.named_modules())
+    assert len(static) == 37
+    for path, d in static.items():
+        m = mods[path]
+        if "act" in d:
+            np.testing.assert_allclose(m.act_quant.amax.numpy(), d["act"], rtol=2e-5, atol=1e-7, err_msg=path)
+        else:
+            np.testing.assert_allclose(m._input_quantizer.amax.numpy().reshape(-1), np.asarray(d["x"]).reshape(-1), rtol=2e-5, err_msg=path)
+            np.testing.assert_allclose(m._weight_quantizer.amax.numpy(), d["w"], rtol=2e-5, atol=1e-7, err_msg=path)
+    model.static_keep_f32 = True
+    _set_static(model, static, Qz)
+    batch = ds.collate_batch([ds[0]]); load_data_to_gpu(batch, dev)
+    with torch.no_grad():
+        model(batch)
+    trace = {}
+    OC.run(state, cfg, ds[0]["points"], OC.Recipe(8, 8, True, 0.5, static=static), trace)
+    eng = model.engine()
+    maps = teacher.row_maps(eng, _cp_index_sets(trace))
+    res = teacher.sparse_layers(eng, maps, lambda n: trace["vfe"][0] if n == "vfe" else trace[n])
+    res += teacher.dense_layers(eng, lambda n: trace[n])
+    teacher.report("W150k static PTQ (calibrated on 2 frames), teacher-forced layers of a third frame", res)
+    assert len(res) == len(eng.sparse_convs) + len(eng.dense_convs)
+    _assert_layers(res)
+
+
+# ------------------------------------------------------------------ nuScenes CenterPoint (the config quant_centerpoint.py's no_list targets)
+def test_nuscenes_centerpoint_full_size(dev):
+    """cbgs_voxel0075_res3d_centerpoint.yaml at its real size (VERDICT r2 missing #4): grid 1440 x 1440 x 40, BEV 180 x 180, six heads /
+    ten classes, 43 quantised dense convs in grouped launches. fp32 model end to end; SmoothQuant w8a8: every layer teacher-forced
+    and head + decode + NMS on the oracle's BEV features (quant/quant_centerpoint.py:20,28-71)."""
+    from amdq3d import quant as Qz
+    cfg = _full_cfg("nuscenes")
+    ds, model = build_model(cfg, n_points=40000, n_voxels=20000, n_frames=1)
+    model.voxel_capacity = 32768
+    state = _state(model)
+    pts = ds[0]["points"]
+    model.cuda()
+    pred = _run_gpu(model, ds, 0, dev)
+    trace = {}
+    b_ref, s_ref, l_ref = OC.run(state, cfg, pts, None, trace)
+    eng = model.engine()
+    assert eng.grid_size == [1440, 1440, 40] and len(eng.heads) == 6 and tuple(eng.bev_cat.shape[1:3]) == (180, 180)
+    teacher.row_maps(eng, _cp_index_sets(trace))
+    pb, ps, pl = _preds(pred)
+    print("nuScenes CenterPoint fp32 (180 x 180, 6 heads): %d boxes (oracle %d)" % (len(ps), len(s_ref)))
+    assert len(s_ref) > 20 and pb.shape[1] == 9
+    assert abs(len(ps) - len(s_ref)) <= max(2, len(s_ref) // 50)
+    assert match_boxes(b_ref, s_ref, l_ref, pb, ps, pl) >= 0.98
+    assert match_boxes(pb, ps, pl, b_ref, s_ref, l_ref) >= 0.98
+    Qz.quant(model, 8, 8, sq=True, alpha=0.5, static=False)
+    model.cuda()
+    _run_gpu(model, ds, 0, dev)
+    trace = {}
+    b_ref, s_ref, l_ref = OC.run(state, cfg, pts, OC.Recipe(8, 8, True, 0.5), trace)
+    eng = model.engine()
+    maps = teacher.row_maps(eng, _cp_index_sets(trace))
+    res = teacher.sparse_layers(eng, maps, lambda n: trace["vfe"][0] if n == "vfe" else trace[n])
+    res += teacher.dense_layers(eng, lambda n: trace[n])
+    teacher.report("nuScenes CenterPoint SmoothQuant w8a8 (180 x 180), teacher-forced layers", res)
+    n_q = sum(1 for r in eng.dense_convs if r["kind"] == "i8")
+    assert n_q == 43 and len(res) == len(eng.sparse_convs) + len(eng.dense_convs)
+    _assert_layers(res)
+    bev = trace["spatial_features_2d"][0].permute(1, 2, 0).numpy()
+    B = eng.run_head_from(torch.from_numpy(np.ascontiguousarray(bev))[None].to(dev))
+    hb, hs, hl = _preds(eng.collect(B)[0])
+    print("   int8 heads + decode + NMS on the oracle's BEV features: %d boxes (oracle %d)" % (len(hs), len(s_ref)))
+    assert len(s_ref) > 20
+    assert match_boxes(b_ref, s_ref, l_ref, hb, hs, hl) >= 0.98
+    assert match_boxes(hb, hs, hl, b_ref, s_ref, l_ref) >= 0.98
