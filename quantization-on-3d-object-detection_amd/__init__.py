@@ -46,9 +46,9 @@ def _guard_graph_replay():
     if started or (started is None and "torch" in _sys.modules):
         return False        # too late: the runtime has read (or may have read) its settings without the flag
     _os.environ[_FLAG] = "0"
-    # forward_async keeps four frames in flight on eight HIP streams (index + main stream of four device plans): give each
-    # stream a hardware queue of its own (the runtime's default is 4, which multiplexes two streams per queue: 507 instead of
-    # 555 frames/s on the headline workload)
+    # forward_async keeps four frames in flight on four HIP streams (one per device plan; a frame is one linear hipGraph): every
+    # stream gets a hardware queue of its own and the graphs' internal queues the rest (GPU_MAX_HW_QUEUES = 2 / 4 / 8 / 16 with
+    # four plans: 504 / 608 / 754 / 747 frames/s in round 2; the runtime's default is 4)
     _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     return True
 

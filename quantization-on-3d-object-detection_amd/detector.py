@@ -233,8 +233,8 @@ class Detector3DTemplate(nn.Module):
     def _async_engine(self):
         """Round-robin over the device plans of forward_async: four by default (CenterPoint: 3 plans 712, 4 plans 757, 5 plans 636,
         6 plans 659 frames/s; VoxelNeXt: 2 plans 447, 4 plans 552, 6 plans 500), each with its own buffers and ONE HIP stream that
-        carries the frame's hipGraph. One frame per plan is in flight at any time; nothing orders the frames of different plans
-        against each other — a frame's kernels are latency chains with tile-quantisation tails, and the other frames' kernels fill
+        carries the frame's hipGraph. A plan's frames are ordered by its stream and it keeps Engine.NSLOT = 2 result slots, so a second
+        frame may be queued behind the running one; nothing orders the frames of different plans against each other — a frame's kernels are latency chains with tile-quantisation tails, and the other frames' kernels fill
         what they leave idle."""
         primary = self.engine()
         n = max(1, int(self.async_streams))
@@ -303,10 +303,11 @@ class CenterPoint(Detector3DTemplate):
         return self.post_processing(batch_dict)
 
     def forward_async(self, batch_dict):
-        """Enqueue a frame without reading anything back → PendingFrame. One frame per device plan is in flight (the call blocks
-        until the plan's previous frame has finished); a plan keeps Engine.NSLOT result slots, so a PendingFrame stays readable
-        until NSLOT later frames have been enqueued on ITS plan (after that counts()/result() raise). Enqueue
-        frame N+1, then call .result() of frame N (serving loops hide the host-side launch work behind the GPU this way)."""
+        """Enqueue a frame without reading anything back → PendingFrame. Plans are taken round-robin; a plan keeps Engine.NSLOT = 2
+        result slots, so up to NSLOT frames may be queued on one plan (the call blocks only until the frame whose result slot it takes
+        over has finished) and a PendingFrame stays readable until NSLOT later frames have been enqueued on ITS plan (after that
+        counts()/result() raise). Enqueue frame N+1, then call .result() of frame N (serving loops hide the host-side launch work
+        behind the GPU this way). counts()/result() raise ValueError if the frame outgrew an index level's row capacity."""
         if self.training:
             raise NotImplementedError("inference-only build: call model.eval() (training is outside the hot path)")
         B = int(batch_dict["batch_size"])

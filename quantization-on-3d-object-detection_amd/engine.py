@@ -1142,9 +1142,9 @@ class Engine:
 
     def _phase(self, key, enqueue):
         if self._graph_now and not self._warm_now and self.use_graph:
-            try:
-                g = self._graphs.get(key)
-                if g is None:
+            g = self._graphs.get(key)
+            if g is None:
+                try:
                     torch.cuda.synchronize(self.device)
                     g = torch.cuda.CUDAGraph()
                     cur = torch.cuda.current_stream(self.device)
@@ -1152,13 +1152,15 @@ class Engine:
                     with torch.cuda.graph(g, stream=cap):
                         enqueue()
                     self._graphs[key] = g
-                g.replay()
+                except Exception as e:      # CAPTURE is an optimisation: fall back to eager launches, once, loudly
+                    import warnings
+                    warnings.warn("hipGraph capture failed (%r); this engine continues with eager launches" % (e,))
+                    self.use_graph = False
+                    self._graphs = {}
+                    g = None
+            if g is not None:
+                g.replay()                  # an error of the replay itself propagates
                 return
-            except Exception as e:      # capture is an optimisation: fall back to eager launches, once, loudly
-                import warnings
-                warnings.warn("hipGraph capture failed (%r); this engine continues with eager launches" % (e,))
-                self.use_graph = False
-                self._graphs = {}
         enqueue()
 
     def _enqueue(self, batch_dict, B, exact_limit=False):

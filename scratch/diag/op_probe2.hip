@@ -116,7 +116,20 @@ __global__ __launch_bounds__(64) void op_probe2_kernel(float *ref, int have_ref,
     probe<7>(gid, lds, ref, have_ref, counters);
     if (threadIdx.x == 0) { atomicAdd(&counters[30], 64); if (blockIdx.x == 0) atomicAdd(&counters[31], 1); }
 }
+// Discriminating variant: ONLY the two smallest formulations — few registers, no scratch in either build — so that the
+// pk / nopk pair differs in instruction FORM alone, not in register footprint, occupancy or private-segment use.
+__global__ __launch_bounds__(64) void op_probe2_small_kernel(float *ref, int have_ref, int *counters) {
+    const unsigned gid = blockIdx.x * 64 + threadIdx.x;
+    probe<6>(gid, nullptr, ref, have_ref, counters);
+    probe<7>(gid, nullptr, ref, have_ref, counters);
+    if (threadIdx.x == 0) { atomicAdd(&counters[30], 64); if (blockIdx.x == 0) atomicAdd(&counters[31], 1); }
+}
 }  // namespace
+
+extern "C" int CAT(CAT(aq3d_diag_op_probe2_, PROBE_TAG), _small)(float *ref, int32_t blocks, int32_t have_ref, int32_t *counters, void *stream) {
+    hipLaunchKernelGGL(CAT(probe_, PROBE_TAG)::op_probe2_small_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, ref, have_ref, counters);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 extern "C" int CAT(aq3d_diag_op_probe2_, PROBE_TAG)(float *ref, int32_t blocks, int32_t have_ref, int32_t *counters, void *stream) {
     hipLaunchKernelGGL(CAT(probe_, PROBE_TAG)::op_probe2_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, ref, have_ref, counters);

@@ -26,7 +26,9 @@ NAMES2 = ["rotated_overlap (production function)", "seg_intersection x16 + corne
           "the divisions only (unconditional)", "ONE seg_intersection"]
 BLOCKS = int(os.environ.get("BLOCKS", "256"))
 PROBES = []
-for sym, names in (("aq3d_diag_op_probe", NAMES), ("aq3d_diag_op_probe2_pk", NAMES2), ("aq3d_diag_op_probe2_nopk", NAMES2)):
+for sym, names in (("aq3d_diag_op_probe", NAMES), ("aq3d_diag_op_probe2_pk", NAMES2), ("aq3d_diag_op_probe2_nopk", NAMES2),
+                   # only formulations 6 and 7 per kernel — 98 (pk) / 38 (nopk) VGPRs, no scratch in either build
+                   ("aq3d_diag_op_probe2_pk_small", NAMES2), ("aq3d_diag_op_probe2_nopk_small", NAMES2)):
     fn = getattr(diag, sym)
     fn.argtypes = [P, ctypes.c_int32, ctypes.c_int32, P, P]
     fn.restype = ctypes.c_int32

@@ -72,7 +72,7 @@ def test_graph_replay_and_two_frames_in_flight_match_eager(dev):
 
 def test_graph_replay_survives_later_allocations_and_a_second_plan(dev):
     """Regression for ROCm's graph packet-capture path (see the package __init__): memory allocated and written AFTER a capture
-    must not change what a replay computes. Also the pipelined forward_async (two plans, index phase one frame ahead)."""
+    must not change what a replay computes. Also the pipelined forward_async (two plans, one linear hipGraph per frame)."""
     import amdq3d
     assert amdq3d.GRAPH_REPLAY_SAFE and os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
     ds, model = _model()

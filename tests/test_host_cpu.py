@@ -431,3 +431,18 @@ def test_library_holds_no_packed_fp32_instructions(tmp_path):
         bad += [l.strip() for l in asm.splitlines() if re.search(r"\bv_pk_(add|mul|fma)_f32\b", l)]
     assert n_inst > 10000, "the disassembly looks empty"
     assert not bad, "packed-fp32 instructions in libaq3d.so (build.py::NO_PACKED_FP32 lost?): %s" % bad[:5]
+    # the A/B that blamed the packed forms also differed in register footprint (196 VGPRs + scratch against 132, none).
+    # Whatever the mechanism, the geometry kernels must stay clear of BOTH: <= 128 VGPRs (no wave save / restore pressure, >= 4
+    # waves per SIMD) and no private segment.
+    readelf = os.path.join(os.path.dirname(objdump), "llvm-readelf")
+    seen = {}
+    for o in objs:
+        notes = subprocess.run([readelf, "--notes", str(o)], check=True, capture_output=True, text=True).stdout
+        for blk in notes.split("- .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            if name and re.search(r"nms_mask_kernel|boxes_iou3d_kernel", name.group(1)):
+                seen[name.group(1)] = (int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)),
+                                       int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)))
+    assert len(seen) == 2, seen
+    for k, (vgpr, scratch) in seen.items():
+        assert vgpr <= 128 and scratch == 0, (k, vgpr, scratch)
