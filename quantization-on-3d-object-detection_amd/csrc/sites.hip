@@ -364,39 +364,29 @@ struct MergeSrc {
     int n, C;
 };
 
-__global__ __launch_bounds__(IX_BLOCK) void ix_merge_bits(MergeSrc S, Lv Out, IxWs ws) {
-    __shared__ int lds4[IX_BLOCK / 64];
-    __shared__ int flag;
-    const int w = blockIdx.x * IX_BLOCK + threadIdx.x;
-    int pc = 0;
-    if (w < Out.words) {
-        int t = w;
-        const int px = t % Out.PX; t /= Out.PX;
-        const int py = t % Out.PY; t /= Out.PY;
-        const int b = t / Out.Z;             // Out.Z == 1
-        unsigned long long bits = 0;
+// one wave per output word, one lane per cell (the 2-D level has few words and every cell asks <= 3 levels x Z slices)
+__global__ __launch_bounds__(IX_BLOCK) void ix_merge_bits(MergeSrc S, Lv Out) {
+    const int w = blockIdx.x * (IX_BLOCK / 64) + (threadIdx.x >> 6), bit = threadIdx.x & 63;
+    if (w >= Out.words) return;
+    int t = w;
+    const int px = t % Out.PX; t /= Out.PX;
+    const int py = t % Out.PY; t /= Out.PY;
+    const int b = t / Out.Z;             // Out.Z == 1
+    const int y = py * 8 + (bit >> 3), x = px * 8 + (bit & 7);
+    bool hit = false;
+    if (y < Out.Y && x < Out.X) {
         for (int l = 0; l < S.n; ++l) {
             const int sc = S.scale[l];
-            for (int bit = 0; bit < 64; ++bit) {
-                const int y = py * 8 + (bit >> 3), x = px * 8 + (bit & 7);
-                if (y % sc != 0 || x % sc != 0) continue;
-                const int iy = y / sc, ix = x / sc;
-                if (iy >= S.L[l].Y || ix >= S.L[l].X) continue;
-                const int pw = lv_word(S.L[l], b, 0, iy >> 3, ix >> 3), pb = ((iy & 7) << 3) | (ix & 7);
-                const int zstride = S.L[l].PY * S.L[l].PX;
-                bool hit = false;
-                for (int z = 0; z < S.L[l].Z && !hit; ++z) hit = (S.L[l].bits[pw + z * zstride] >> pb) & 1ull;
-                if (hit) bits |= 1ull << bit;
-            }
+            if (y % sc != 0 || x % sc != 0) continue;
+            const int iy = y / sc, ix = x / sc;
+            if (iy >= S.L[l].Y || ix >= S.L[l].X) continue;
+            const int pw = lv_word(S.L[l], b, 0, iy >> 3, ix >> 3), pb = ((iy & 7) << 3) | (ix & 7);
+            const int zstride = S.L[l].PY * S.L[l].PX;
+            for (int z = 0; z < S.L[l].Z; ++z) hit |= (S.L[l].bits[pw + z * zstride] >> pb) & 1ull;
         }
-        bits &= ix_valid_mask(Out, py, px);
-        Out.bits[w] = bits;
-        pc = __popcll(bits);
     }
-    int tot;
-    (void)ix_block_scan(pc, lds4, &tot);
-    if (threadIdx.x == 0) __hip_atomic_store(&ws.chunk_sums[blockIdx.x], tot, IX_AGENT);
-    if (ix_arrive(ws.ticket, gridDim.x, &flag)) ix_scan_chunks(ws.chunk_sums, gridDim.x, Out, ws.ticket, lds4);
+    const unsigned long long bits = __builtin_amdgcn_ballot_w64(hit);
+    if (bit == 0) Out.bits[w] = bits;
 }
 
 // thread = (output row, 4 channels): sum of the contributing rows in (level, z) order — no float atomics, bit-reproducible
@@ -845,7 +835,8 @@ extern "C" int aq3d_level_merge(const aq3d_level *const *levels, const int32_t *
         aq3d_set_error("aq3d_level_merge: workspace too small");
         return AQ3D_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(ix_merge_bits, dim3(ix_words_grid(Out)), dim3(IX_BLOCK), 0, stream, S, Out, ws);
+    hipLaunchKernelGGL(ix_merge_bits, dim3(aq3d_div_up(Out.words, IX_BLOCK / 64)), dim3(IX_BLOCK), 0, stream, S, Out);
+    hipLaunchKernelGGL(ix_count, dim3(aq3d_div_up(ix_words_grid(Out), IX_CPB)), dim3(IX_BLOCK), 0, stream, Out, ws, ix_words_grid(Out));
     ix_number_rows(Out, ws, stream);
     AQ3D_CHECK_LAUNCH("aq3d_level_merge");
     return AQ3D_OK;

@@ -259,7 +259,8 @@ def test_s40k_voxelnext_int8_head_on_the_oracle_features(dev, s40k):
     ORACLE's shared_conv features: boxes at the north-star tolerance (the CenterPoint counterpart is test (iv) above)."""
     from amdq3d import quant as Qz
     cfg, ds, model, state, pts = (s40k[k] for k in ("cfg", "ds", "model", "state", "pts"))
-    Qz.dynamic_quant_voxelnext(model, 8, 8, sq=True)
+    if not any(isinstance(m, Qz.QConvNd) for m in model.modules()):      # the module-scoped model may already carry the recipe
+        Qz.dynamic_quant_voxelnext(model, 8, 8, sq=True)
     model.cuda()
     _run_gpu(model, ds, 0, dev)
     trace = {}
