@@ -109,13 +109,16 @@ int aq3d_mean_vfe(const float *voxels, const float *num_points, int32_t m, int32
  *   count       i32 [1]       live rows = min(total[0], cap)
  *   total       i32 [2]       [0] number of active sites (UNclamped: > cap means the level overflowed its buffers and the
  *                             frame is invalid), [1] the largest per-sample number of sites
- * Rows are numbered class by class (sites grouped by which planes of their 3x3x3 neighbourhood are occupied, heaviest
- * class first, raster order inside a class) so that the 128-row tiles of the gather-GEMM kernels skip most kernel offsets. */
+ * Row order: bitmap raster order (flags = 0), or — AQ3D_LEVEL_SORTED — class by class (sites grouped by which planes of their
+ * 3x3x3 neighbourhood are occupied, heaviest class first, raster order inside a class) so that the 128-row tiles of the
+ * gather-GEMM kernels skip most kernel offsets: three more launches per level, worth it for the levels whose convs have >= 128
+ * input channels (W150k: 128-channel layers 67 -> 54 us each; 32 / 64 channels gain 2 us per layer, less than the sort costs). */
+enum { AQ3D_LEVEL_SORTED = 1 };
 typedef struct aq3d_level {
     int32_t shape[3];          /* z, y, x */
     int32_t batch;             /* samples (<= 64) */
     int32_t cap;               /* row capacity */
-    int32_t reserved;
+    int32_t flags;             /* AQ3D_LEVEL_SORTED */
     uint64_t *bits;
     int32_t *base;
     int32_t *row_of_rank;

@@ -182,13 +182,23 @@ __device__ __forceinline__ void topk_per_class_body(const float *__restrict__ hm
             }
             if (threadIdx.x == 0) s_filtered = 1;
             L = total;
+        } else {
+            // too many scores above the threshold (a heat map that hovers around it): the keys just computed ARE the key cache of
+            // the unfiltered path — store them instead of loading and evaluating every pixel a second time
+#pragma unroll
+            for (int it = 0; it < FPER; ++it) {
+                const int i = beg + it * 64 + lane;
+                if (it * 64 < chunk && i < end) keys_s[i] = kv[it];
+            }
+            if (threadIdx.x == 0) s_filtered = 2;
         }
         __syncthreads();
     }
-    const bool filtered = try_filter && s_filtered;
+    const bool filtered = try_filter && s_filtered == 1;
+    const bool keys_cached = try_filter && s_filtered == 2;
     const int Keff = K < L ? K : L;
     auto orig = [&](int i) -> unsigned int { return filtered ? idx_s[i] : (unsigned int)i; };
-    if (cache_keys && !filtered) {
+    if (cache_keys && !filtered && !keys_cached) {
         // strided column read (one float per pixel row): 8 independent loads in flight per thread
         const int nth = blockDim.x;
         for (int base = threadIdx.x; base < L; base += 8 * nth) {

@@ -25,6 +25,7 @@
 
 struct Lv {
     int Z, Y, X, B, cap, PY, PX, words;
+    int sorted;         // rows numbered class by class (AQ3D_LEVEL_SORTED) or in bitmap raster order
     unsigned long long *bits;
     int *base, *rank2row, *coords, *count, *total;
 };
@@ -84,6 +85,7 @@ static int lv_of(const aq3d_level *l, Lv *o, const char *who) {
     AQ3D_REQUIRE(words * 64 < (int64_t)0x7fffffff, "%s: grid of %lld cells overflows 32-bit cell ids", who, (long long)words * 64);
     o->Z = l->shape[0]; o->Y = l->shape[1]; o->X = l->shape[2]; o->B = l->batch; o->cap = l->cap;
     o->PY = (o->Y + 7) / 8; o->PX = (o->X + 7) / 8; o->words = (int)words;
+    o->sorted = (l->flags & AQ3D_LEVEL_SORTED) ? 1 : 0;
     o->bits = (unsigned long long *)l->bits; o->base = l->base; o->rank2row = l->row_of_rank; o->coords = l->coords;
     o->count = l->count; o->total = l->total;
     return AQ3D_OK;
@@ -189,7 +191,7 @@ __device__ __forceinline__ void ix_scan_chunks(int *chunk_sums, int n, const Lv 
     }
     if (threadIdx.x == 0) {
         L.total[0] = tot;
-        L.total[1] = 0;
+        L.total[1] = L.B == 1 ? tot : 0;        // per-sample maximum: the total itself for one sample, else ix_offsets / ix_sample_max
         *L.count = tot < L.cap ? tot : L.cap;
         __hip_atomic_store(ticket, 0, IX_AGENT);
     }
@@ -428,11 +430,37 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_rank(Lv L, IxWs ws) {
     L.base[w] = r;
     const int per_sample = L.words / L.B;
     if (w % per_sample == 0) ws.sstart[w / per_sample] = r;
+    if (L.sorted) {
+        while (v) {
+            const int bit = __builtin_ctzll(v);
+            if (r < L.cap) ws.cell_of_rank[r] = w * 64 + bit;
+            ++r;
+            v &= v - 1ull;
+        }
+        return;
+    }
+    // raster-ordered level: row = rank, the level is complete after this kernel
+    int t = w;
+    const int px = t % L.PX; t /= L.PX;
+    const int py = t % L.PY; t /= L.PY;
+    const int z = t % L.Z, b = t / L.Z;
     while (v) {
         const int bit = __builtin_ctzll(v);
-        if (r < L.cap) ws.cell_of_rank[r] = w * 64 + bit;
+        if (r < L.cap) {
+            L.rank2row[r] = r;
+            reinterpret_cast<int4 *>(L.coords)[r] = make_int4(b, z, py * 8 + (bit >> 3), px * 8 + (bit & 7));
+            ws.head[r] = -1;
+        }
         ++r;
         v &= v - 1ull;
+    }
+}
+
+// batch > 1, raster-ordered level: the largest per-sample number of sites (MAX_NUMBER_OF_VOXELS is a per-sample limit)
+__global__ void ix_sample_max(Lv L, IxWs ws) {
+    if ((int)threadIdx.x < L.B) {
+        const int s0 = ws.sstart[threadIdx.x], s1 = (int)threadIdx.x + 1 < L.B ? ws.sstart[threadIdx.x + 1] : L.total[0];
+        atomicMax(&L.total[1], s1 - s0);
     }
 }
 
@@ -503,7 +531,7 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_offsets(Lv L, IxWs ws) {
     }
     if (threadIdx.x == 0) ws.cls_tot[c] = carry;
     // per-sample totals (max_voxels is a per-sample limit, data_processor.py:45-61)
-    if (c == 0 && threadIdx.x < L.B) {
+    if (c == 0 && L.B > 1 && threadIdx.x < L.B) {
         const int s0 = ws.sstart[threadIdx.x], s1 = threadIdx.x + 1 < L.B ? ws.sstart[threadIdx.x + 1] : L.total[0];
         atomicMax(&L.total[1], s1 - s0);
     }
@@ -701,6 +729,10 @@ static int ix_words_grid(const Lv &L) { return aq3d_div_up(L.words, IX_BLOCK); }
 // rank / class / scatter of a level whose bitmap and chunk sums are complete
 static void ix_number_rows(const Lv &L, const IxWs &ws, hipStream_t stream) {
     hipLaunchKernelGGL(ix_rank, dim3(ix_words_grid(L)), dim3(IX_BLOCK), 0, stream, L, ws);
+    if (!L.sorted) {
+        if (L.B > 1) hipLaunchKernelGGL(ix_sample_max, dim3(1), dim3(64), 0, stream, L, ws);
+        return;
+    }
     const int rblocks = aq3d_div_up(L.cap, IX_BLOCK);
     hipLaunchKernelGGL(ix_class, dim3(rblocks), dim3(IX_BLOCK), 0, stream, L, ws);
     hipLaunchKernelGGL(ix_offsets, dim3(128), dim3(IX_BLOCK), 0, stream, L, ws);

@@ -152,6 +152,7 @@ class Engine:
             self.fully_sparse = False
             self._build_sparse(det.backbone_3d)
             self._build_dense(det.backbone_2d, det.dense_head)
+        self._decide_row_order()
         self.arena.finalize()
         # A frame is ONE linear launch plan (voxelizer, index chain, sparse convs, BEV, head, decode) = one captured hipGraph on one
         # stream. Rounds 1-2 ran CenterPoint's index chain as a phase of its own on a second stream, one frame ahead, and VoxelNeXt's
@@ -183,6 +184,15 @@ class Engine:
         return t.to(self.device)
 
     # ------------------------------------------------------------------ sparse plan primitives
+    def _decide_row_order(self):
+        """Class-sorted rows (AQ3D_LEVEL_SORTED: three more launches per level and frame) only where they pay: levels whose quantised
+        submanifold convs have >= 128 input channels (W150k: 67 -> 54 us per 128-channel layer; 2 us per 32- / 64-channel layer, less
+        than the sort costs; none at 16 channels)."""
+        for li, lv in enumerate(self.levels):
+            wide = any(r.get("coded") and r["level"] == li and r["nbr"] == li and r["cin"] >= 128 for r in self.sparse_convs)
+            lv["index"].c.flags = 1 if wide else 0
+            lv["index"].sorted_rows = wide
+
     def _level_cap(self, li, shape, bound=None):
         """Row capacity of level li (see __init__): override, else min(cells, bound, factor x level-0 capacity)."""
         if li in self.level_caps:

@@ -58,7 +58,7 @@ class SpconvProblem(Structure):
 
 
 class Level(Structure):
-    _fields_ = [("shape", c_int32 * 3), ("batch", c_int32), ("cap", c_int32), ("reserved", c_int32), ("bits", c_void_p),
+    _fields_ = [("shape", c_int32 * 3), ("batch", c_int32), ("cap", c_int32), ("flags", c_int32), ("bits", c_void_p),
                 ("base", c_void_p), ("row_of_rank", c_void_p), ("coords", c_void_p), ("count", c_void_p), ("total", c_void_p)]
 
 

@@ -86,7 +86,7 @@ def mean_vfe(voxels, num_points, rows=None, out=None):
 class IndexLevel:
     """Device arrays of one index level (include/aq3d.h: aq3d_level) + the ctypes struct that names them."""
 
-    def __init__(self, shape, batch, cap, device, stats=None):
+    def __init__(self, shape, batch, cap, device, stats=None, sorted_rows=True):
         L = _lib.load()
         self.shape, self.batch, self.cap = [int(v) for v in shape], int(batch), int(cap)
         self.words = int(L.aq3d_level_words(I3(*self.shape), self.batch))
@@ -100,7 +100,8 @@ class IndexLevel:
         c = _lib.Level()
         for j in range(3):
             c.shape[j] = self.shape[j]
-        c.batch, c.cap, c.reserved = self.batch, self.cap, 0
+        c.batch, c.cap, c.flags = self.batch, self.cap, (1 if sorted_rows else 0)       # AQ3D_LEVEL_SORTED
+        self.sorted_rows = bool(sorted_rows)
         c.bits, c.base, c.row_of_rank = self.bits.data_ptr(), self.base.data_ptr(), self.row_of_rank.data_ptr()
         c.coords, c.count, c.total = self.coords.data_ptr(), self.count.data_ptr(), self.total.data_ptr()
         self.c = c

@@ -83,10 +83,10 @@ def _sparse_input(dev, m_pts=6000, seed=3, batch=2):
     return idx, shape
 
 
-def _level_of(dev, idx, shape, batch, extra_cap=100):
+def _level_of(dev, idx, shape, batch, extra_cap=100, sorted_rows=True):
     """Index level built from the given sites → (level, rows): oracle row i lives in device row rows[i]."""
     from amdq3d import ops
-    lv = ops.IndexLevel(shape, batch, len(idx) + extra_cap, dev)
+    lv = ops.IndexLevel(shape, batch, len(idx) + extra_cap, dev, sorted_rows=sorted_rows)
     rows = ops.level_from_coords(torch.from_numpy(np.ascontiguousarray(idx)).to(dev), lv).cpu().numpy()
     n, total, _ = lv.live()
     assert n == total == len(idx)
@@ -100,11 +100,17 @@ def _renumber(nbr_ref, rows_in):
     return np.where(nbr_ref >= 0, rows_in[np.maximum(nbr_ref, 0)], -1)
 
 
+@pytest.mark.parametrize("sorted_rows", [True, False])
 @pytest.mark.parametrize("ksize", [(3, 3, 3), (1, 3, 3), (1, 1, 1)])
-def test_subm_neighbors_exact(dev, ksize):
+def test_subm_neighbors_exact(dev, ksize, sorted_rows):
     from amdq3d import ops
     idx, shape = _sparse_input(dev)
-    lv, rows = _level_of(dev, idx, shape, 2)
+    lv, rows = _level_of(dev, idx, shape, 2, sorted_rows=sorted_rows)
+    if not sorted_rows:         # raster order of the bitmap: (b, z, y / 8, x / 8, y % 8, x % 8)
+        i64 = idx.astype(np.int64)
+        PY, PX = (shape[1] + 7) // 8, (shape[2] + 7) // 8
+        key = (((i64[:, 0] * shape[0] + i64[:, 1]) * PY + (i64[:, 2] >> 3)) * PX + (i64[:, 3] >> 3)) * 64 + (i64[:, 2] & 7) * 8 + (i64[:, 3] & 7)
+        np.testing.assert_array_equal(np.argsort(key), np.argsort(rows))
     nbr = ops.subm_neighbors(lv, ksize)[:len(idx)].cpu().numpy()
     np.testing.assert_array_equal(nbr[rows], _renumber(OS.subm_neighbors(idx, shape, ksize), rows))
 
@@ -139,9 +145,9 @@ def test_level_downsample_exact(dev, ksize, stride, pad):
     from amdq3d import ops
     idx, shape = _sparse_input(dev, seed=5)
     shape = [41, 157, 163]                        # not multiples of 8: edge patches
-    lv_in, rows_in = _level_of(dev, idx, shape, 2, extra_cap=17)
+    lv_in, rows_in = _level_of(dev, idx, shape, 2, extra_cap=17, sorted_rows=stride[0] == 2)      # both row orders on the input side
     o_ref, nbr_ref, oshape = OS.conv_outputs(idx, shape, ksize, stride, pad)
-    lv_out = ops.IndexLevel(oshape, 2, len(o_ref) + 33, dev)
+    lv_out = ops.IndexLevel(oshape, 2, len(o_ref) + 33, dev, sorted_rows=ksize[0] == 3)
     ops.level_downsample(lv_in, ksize, stride, pad, lv_out)
     m, total, _ = lv_out.live()
     assert m == total == len(o_ref)
