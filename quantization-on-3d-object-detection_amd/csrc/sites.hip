@@ -242,28 +242,31 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_mark_coords(const int *__restrict
 }
 
 // sites per 256-word chunk + (last workgroup) their exclusive scan. A workgroup counts IX_CPB chunks and takes ONE ticket: the
-// arrival counter is a single word and saturates at ~88 adds per microsecond (the voxel level of a Waymo grid has 5 664 chunks).
+// arrival counter is a single word (the voxel level of a Waymo grid has 5 664 chunks). Measured: 8 or 32 chunks per workgroup and
+// 8- or 16-byte loads all give 21-24 us for that level — the pass is bound by reading the 11.6 MB bitmap the memset and the
+// points' atomics have just written, not by the tickets.
 #define IX_CPB 8
 __global__ __launch_bounds__(IX_BLOCK) void ix_count(Lv L, IxWs ws, int nchunks) {
     __shared__ int lds4[IX_BLOCK / 64];
-    __shared__ int part[IX_CPB][IX_BLOCK / 64];
+    __shared__ int part[IX_CPB][2];
     __shared__ int flag;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // 16-byte loads: a thread takes two adjacent words, the workgroup two chunks per round (waves 0-1 the first, 2-3 the second)
 #pragma unroll
-    for (int j = 0; j < IX_CPB; ++j) {
-        const int w = (blockIdx.x * IX_CPB + j) * IX_BLOCK + threadIdx.x;
-        int pc = w < L.words ? __popcll(L.bits[w]) : 0;
+    for (int jj = 0; jj < IX_CPB / 2; ++jj) {
+        const int w = (blockIdx.x * IX_CPB + 2 * jj) * IX_BLOCK + 2 * threadIdx.x;
+        int pc = 0;
+        if (w + 1 < L.words) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(L.bits + w);
+            pc = __popcll(v.x) + __popcll(v.y);
+        } else if (w < L.words) pc = __popcll(L.bits[w]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) pc += __shfl_xor(pc, off, 64);
-        if (lane == 0) part[j][wave] = pc;
+        if (lane == 0) part[2 * jj + (wave >> 1)][wave & 1] = pc;
     }
     __syncthreads();
-    if (threadIdx.x < IX_CPB && blockIdx.x * IX_CPB + threadIdx.x < nchunks) {
-        int tot = 0;
-#pragma unroll
-        for (int w = 0; w < IX_BLOCK / 64; ++w) tot += part[threadIdx.x][w];
-        __hip_atomic_store(&ws.chunk_sums[blockIdx.x * IX_CPB + threadIdx.x], tot, IX_AGENT);
-    }
+    if (threadIdx.x < IX_CPB && blockIdx.x * IX_CPB + threadIdx.x < nchunks)
+        __hip_atomic_store(&ws.chunk_sums[blockIdx.x * IX_CPB + threadIdx.x], part[threadIdx.x][0] + part[threadIdx.x][1], IX_AGENT);
     if (ix_arrive(ws.ticket, gridDim.x, &flag)) ix_scan_chunks(ws.chunk_sums, nchunks, L, ws.ticket, lds4);
 }
 
@@ -332,30 +335,78 @@ __device__ __forceinline__ unsigned long long ix_valid_mask(const Lv &L, int py,
     return m;
 }
 
-__global__ __launch_bounds__(IX_BLOCK) void ix_dilate(Lv In, Lv Out, Geo g, IxWs ws) {
+// The same for the common window — 3x3 in (y, x), stride 2, padding 1 — on whole words: every row of a patch is dilated and
+// compressed by 64-bit mask / shift operations (8 rows per instruction instead of one), ~5x fewer instructions than the row loop.
+__device__ __forceinline__ unsigned long long ix_even_cols(unsigned long long v) {        // bits 0, 2, 4, 6 of every byte -> its low nibble
+    v &= 0x5555555555555555ull;
+    v = (v | (v >> 1)) & 0x3333333333333333ull;
+    v = (v | (v >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    return v;
+}
+__device__ __forceinline__ unsigned long long ix_even_rows(unsigned long long v) {        // bytes 0, 2, 4, 6 -> the low 32 bits
+    v &= 0x00ff00ff00ff00ffull;
+    v = (v | (v >> 8)) & 0x0000ffff0000ffffull;
+    v = (v | (v >> 16)) & 0x00000000ffffffffull;
+    return v;
+}
+__device__ __forceinline__ unsigned long long ix_dilate_plane_s2(const Lv &In, int b, int iz, int opy, int opx) {
+    unsigned long long H[3];
+    unsigned long long any = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {                        // input patch rows 2 opy - 1, 2 opy, 2 opy + 1
+        const int py = 2 * opy - 1 + a;
+        unsigned long long A = 0, B = 0, C = 0;         // input patch columns 2 opx - 1, 2 opx, 2 opx + 1
+        if (py >= 0 && py < In.PY) {
+            const int w = lv_word(In, b, iz, py, 0), px = 2 * opx;
+            if (px - 1 >= 0) A = In.bits[w + px - 1];
+            if (px < In.PX) B = In.bits[w + px];
+            if (px + 1 < In.PX) C = In.bits[w + px + 1];
+        }
+        any |= A | B | C;
+        // bit c of tB = B[c-1] | B[c] | B[c+1] (column -1 = column 7 of A); of tC likewise with column 7 of B
+        const unsigned long long tB = B | ((B >> 1) & 0x7f7f7f7f7f7f7f7full) | ((B << 1) & 0xfefefefefefefefeull) | ((A >> 7) & 0x0101010101010101ull);
+        const unsigned long long tC = C | ((C >> 1) & 0x7f7f7f7f7f7f7f7full) | ((C << 1) & 0xfefefefefefefefeull) | ((B >> 7) & 0x0101010101010101ull);
+        H[a] = ix_even_cols(tB) | (ix_even_cols(tC) << 4);          // output columns 0-3 | 4-7 of the patch row's 8 input rows
+    }
+    if (!any) return 0ull;
+    // rows: output row oy <- input rows 2 oy - 1, 2 oy, 2 oy + 1 (row -1 = row 7 of the patch above)
+    const unsigned long long vM = H[1] | (H[1] >> 8) | (H[1] << 8) | (H[0] >> 56);
+    const unsigned long long vN = H[2] | (H[2] >> 8) | (H[2] << 8) | (H[1] >> 56);
+    return ix_even_rows(vM) | (ix_even_rows(vN) << 32);
+}
+
+#define IX_DPB 1        // 256-word chunks per workgroup of ix_dilate (4 per workgroup: 12 -> 25 us, the words of a thread run serially)
+__global__ __launch_bounds__(IX_BLOCK) void ix_dilate(Lv In, Lv Out, Geo g, IxWs ws, int nchunks) {
     __shared__ int lds4[IX_BLOCK / 64];
     __shared__ int flag;
-    const int w = blockIdx.x * IX_BLOCK + threadIdx.x;
-    int pc = 0;
-    if (w < Out.words) {
-        int t = w;
-        const int px = t % Out.PX; t /= Out.PX;
-        const int py = t % Out.PY; t /= Out.PY;
-        const int oz = t % Out.Z, b = t / Out.Z;
-        unsigned long long bits = 0;
+    const bool s2 = g.ky == 3 && g.kx == 3 && g.sy == 2 && g.sx == 2 && g.py == 1 && g.px == 1;       // wave-uniform
+    const bool flat = g.ky == 1 && g.kx == 1 && g.sy == 1 && g.sx == 1 && g.py == 0 && g.px == 0;     // window in z only
+    for (int j = 0; j < IX_DPB; ++j) {
+        const int chunk = blockIdx.x * IX_DPB + j;
+        if (chunk >= nchunks) break;                     // uniform per workgroup
+        const int w = chunk * IX_BLOCK + threadIdx.x;
+        int pc = 0;
+        if (w < Out.words) {
+            int t = w;
+            const int px = t % Out.PX; t /= Out.PX;
+            const int py = t % Out.PY; t /= Out.PY;
+            const int oz = t % Out.Z, b = t / Out.Z;
+            unsigned long long bits = 0;
 #pragma unroll
-        for (int kz = 0; kz < 3; ++kz) {
-            const int iz = oz * g.sz - g.pz + kz;
-            if (kz < g.kz && iz >= 0 && iz < In.Z) bits |= ix_dilate_plane(In, b, iz, py, px, g);
+            for (int kz = 0; kz < 3; ++kz) {
+                const int iz = oz * g.sz - g.pz + kz;
+                if (kz < g.kz && iz >= 0 && iz < In.Z)
+                    bits |= s2 ? ix_dilate_plane_s2(In, b, iz, py, px) : (flat ? In.bits[lv_word(In, b, iz, py, px)] : ix_dilate_plane(In, b, iz, py, px, g));
+            }
+            bits &= ix_valid_mask(Out, py, px);
+            Out.bits[w] = bits;
+            pc = __popcll(bits);
         }
-        bits &= ix_valid_mask(Out, py, px);
-        Out.bits[w] = bits;
-        pc = __popcll(bits);
+        int tot;
+        (void)ix_block_scan(pc, lds4, &tot);
+        if (threadIdx.x == 0) __hip_atomic_store(&ws.chunk_sums[chunk], tot, IX_AGENT);
     }
-    int tot;
-    (void)ix_block_scan(pc, lds4, &tot);
-    if (threadIdx.x == 0) __hip_atomic_store(&ws.chunk_sums[blockIdx.x], tot, IX_AGENT);
-    if (ix_arrive(ws.ticket, gridDim.x, &flag)) ix_scan_chunks(ws.chunk_sums, gridDim.x, Out, ws.ticket, lds4);
+    if (ix_arrive(ws.ticket, gridDim.x, &flag)) ix_scan_chunks(ws.chunk_sums, nchunks, Out, ws.ticket, lds4);
 }
 
 // ------------------------------------------------------------------ VoxelNeXt bev_out: union of <= 3 levels projected onto (y, x)
@@ -831,7 +882,7 @@ extern "C" int aq3d_level_downsample(const aq3d_level *in, const int32_t ksize[3
         aq3d_set_error("aq3d_level_downsample: workspace %zu < %zu bytes", workspace_bytes, aq3d_index_workspace_bytes(Out.cap, Out.words, 0));
         return AQ3D_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(ix_dilate, dim3(ix_words_grid(Out)), dim3(IX_BLOCK), 0, stream, In, Out, g, ws);
+    hipLaunchKernelGGL(ix_dilate, dim3(aq3d_div_up(ix_words_grid(Out), IX_DPB)), dim3(IX_BLOCK), 0, stream, In, Out, g, ws, ix_words_grid(Out));
     ix_number_rows(Out, ws, stream);
     AQ3D_CHECK_LAUNCH("aq3d_level_downsample");
     return AQ3D_OK;
