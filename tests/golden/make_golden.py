@@ -7,6 +7,9 @@
     bev_backbone.npz  pcdet/models/backbones_2d/base_bev_backbone.py::BaseBEVBackbone (fp32) on a seeded input.
 
 Usage (build container only):  python tests/golden/make_golden.py
+
+Kept as the record of how the committed fixtures were produced in round 2. Since round 3 the build environment refuses to execute
+modules of the reference checkout, so this script is no longer run; the .npz files are the pinned data.
 """
 import importlib.util
 import os
