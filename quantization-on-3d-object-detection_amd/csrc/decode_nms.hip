@@ -17,6 +17,16 @@
 
 typedef unsigned long long u64;
 
+// In-kernel clock stamps of the single-workgroup kernels of this file for scratch/dn_stamps.py (diagnostic build with -DAQ3D_STAMPS
+// only; the product library compiles none of it): thread 0 of the first workgroup writes clock64() into slot [kernel][i].
+#ifdef AQ3D_STAMPS
+__device__ unsigned long long *g_dn_stamps;          // [4 kernels][16]
+extern "C" int aq3d_diag_set_dn_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dn_stamps), &p, sizeof(p)); }
+#define DN_STAMP(kernel, i) do { if (g_dn_stamps && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) g_dn_stamps[(kernel) * 16 + (i)] = (unsigned long long)wall_clock64(); } while (0)
+#else
+#define DN_STAMP(kernel, i)
+#endif
+
 // ------------------------------------------------------------------ block-wide helpers (1024 threads)
 __device__ __forceinline__ int block_scan_excl_1024(int v, int *sh, int *total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -123,6 +133,9 @@ __device__ __forceinline__ float sigmoidf_dev(float x) { return __fdiv_rn(1.0f, 
 // chain of a head is a string of single-workgroup, latency-bound launches (~170 us per head), and the 6-head models (nuScenes
 // CenterPoint, VoxelNeXt) ran it six times back to back.
 #define AQ3D_MAX_HEADS 8
+__device__ __forceinline__ void topk_select_tail(const float *__restrict__ col, int hm_ld, int L, bool filtered, int cache_keys, int K, int Kpad,
+                                                 u64 *sel, int *hist, int *sh, unsigned int *keys_s, unsigned int *idx_s,
+                                                 u64 *__restrict__ out, const int cls);
 __device__ __forceinline__ void topk_per_class_body(const float *__restrict__ hm, int hm_ld, int L_static,
                                                     const int *__restrict__ count, int K, int Kpad,
                                                     int cache_keys, float score_thresh, u64 *__restrict__ out, const int cls) {
@@ -133,14 +146,7 @@ __device__ __forceinline__ void topk_per_class_body(const float *__restrict__ hm
     int *hist = reinterpret_cast<int *>(sel + Kpad);       // [256]
     int *sh = hist + 256;                                  // [16]
     unsigned int *keys_s = reinterpret_cast<unsigned int *>(sh + 16);   // [L] score bit patterns (when they fit in LDS)
-    constexpr int TIE_CAP = 512;
-    __shared__ unsigned int s_prefix;
-    __shared__ int s_remaining, s_fill, s_ties;
-    __shared__ unsigned int tie_idx[TIE_CAP];
     const float *col = hm + cls;
-    auto key_of = [&](int i) -> unsigned int {
-        return cache_keys ? keys_s[i] : __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
-    };
     // Pre-filter: a candidate whose score is not above score_thresh is masked by the decode stage whatever its rank, so
     // the top-K only has to be found among the scores above it (if fewer than K exist, the missing ones would be masked
     // anyway). An ORDER-PRESERVING compaction (each wave owns a contiguous pixel range; counts, a 16-wave prefix, then
@@ -196,8 +202,6 @@ __device__ __forceinline__ void topk_per_class_body(const float *__restrict__ hm
     }
     const bool filtered = try_filter && s_filtered == 1;
     const bool keys_cached = try_filter && s_filtered == 2;
-    const int Keff = K < L ? K : L;
-    auto orig = [&](int i) -> unsigned int { return filtered ? idx_s[i] : (unsigned int)i; };
     if (cache_keys && !filtered && !keys_cached) {
         // strided column read (one float per pixel row): 8 independent loads in flight per thread
         const int nth = blockDim.x;
@@ -216,6 +220,24 @@ __device__ __forceinline__ void topk_per_class_body(const float *__restrict__ hm
         }
     }
 
+    topk_select_tail(col, hm_ld, L, filtered, cache_keys, K, Kpad, sel, hist, sh, keys_s, idx_s, out, cls);
+}
+
+// Radix select + tie rule + write-out over L keys: keys_s[0..L) when cache_keys (filtered: idx_s[i] = pixel of candidate i, candidates
+// in ascending pixel order), else recomputed from the map. Every thread of the 1024 calls it; a barrier separates the caller's LDS
+// writes from the first pass.
+__device__ __forceinline__ void topk_select_tail(const float *__restrict__ col, int hm_ld, int L, bool filtered, int cache_keys, int K, int Kpad,
+                                                 u64 *sel, int *hist, int *sh, unsigned int *keys_s, unsigned int *idx_s,
+                                                 u64 *__restrict__ out, const int cls) {
+    constexpr int TIE_CAP = 512;
+    __shared__ unsigned int s_prefix;
+    __shared__ int s_remaining, s_fill, s_ties;
+    __shared__ unsigned int tie_idx[TIE_CAP];
+    auto key_of = [&](int i) -> unsigned int {
+        return cache_keys ? keys_s[i] : __float_as_uint(sigmoidf_dev(col[(size_t)i * hm_ld]));
+    };
+    auto orig = [&](int i) -> unsigned int { return filtered ? idx_s[i] : (unsigned int)i; };
+    const int Keff = K < L ? K : L;
     // 4-pass MSB radix select on the 32-bit score keys: find T = Keff-th largest key
     if (threadIdx.x == 0) { s_prefix = 0u; s_remaining = Keff; }
     __syncthreads();
@@ -237,6 +259,7 @@ __device__ __forceinline__ void topk_per_class_body(const float *__restrict__ hm
                 continue;
             }
             // top byte of a heat-map score: nearly every key shares it → one atomic per wave and distinct value
+            // (measured: the same aggregation on the lower bytes, two rounds then plain atomics, is slower — 41 -> 52 us at 188 x 188)
             u64 active = __ballot(bin != 0xffffffffu);
             while (active) {
                 const int leader = __ffsll((long long)active) - 1;
@@ -340,6 +363,225 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(TopkBatch b) {
     topk_per_class_body(a.hm, a.hm_ld, a.L_static, a.count, a.K, a.Kpad, a.cache_keys, a.score_thresh, a.out, (int)blockIdx.x);
 }
 
+// Dense maps, two launches instead of one workgroup per class. A class column of a [H*W, hm_ld] map is one float per 64-byte line:
+// a single workgroup pulls the whole map (3.4 MB at 188 x 188 x 24) through ONE compute unit's texture path and evaluates 36
+// sigmoids per thread before the select can start, and the select then walks all H*W keys five times on four SIMDs.
+//   topk_scan_kernel    grid (G, classes, heads): workgroup g owns pixels [g*chunk, (g+1)*chunk) (chunk <= 4096, a multiple of 1024),
+//                       wave w of it the contiguous 1/16th; scores -> key bits to keys_all[class][pixel]; keys above the score
+//                       threshold -> order-preserving compaction (wave counts, 16-wave prefix, ballot ranks) into the chunk's own
+//                       candidate range cand[class][g*chunk ..] (composites score << 32 | ~pixel), chunk_cnt[class][g] = how many, and the chunk's histogram
+//                       of the candidates over TK_NB bins of the key's top bits (exponent + 5 mantissa bits: 32 bins per octave).
+//   topk_select_kernel  grid (classes, heads): sums the chunk histograms, finds the bin that holds the K-th score, and in ONE pass over
+//                       the candidates takes every key of a higher bin and collects the pivot bin's keys (normally a few hundred); a
+//                       bitonic sort of those as (score, ~pixel) composites yields the rest with the tie rule built in. More than
+//                       TK_SORT keys in the pivot bin (saturated or constant maps): the general select over keys_all, as before.
+// No cross-workgroup hand-off inside a launch: the kernel boundary is the synchronisation.
+struct ScanArgs {
+    const float *hm;
+    int hm_ld, L, nclass, G, chunk, K, Kpad;
+    float score_thresh;
+    unsigned int *keys_all;                             // [nclass][L]
+    u64 *cand;                                          // [nclass][G*chunk] composites: score bits << 32 | ~pixel
+    int *chunk_cnt, *chunk_hist;                        // [nclass][G], [nclass][G][TK_NB]
+    u64 *out;
+};
+struct ScanBatch {
+    ScanArgs p[AQ3D_MAX_HEADS];
+};
+constexpr int TK_NB = 4096, TK_SH = 18, TK_SORT = 2048, TK_MAXG = 16;
+__device__ __forceinline__ int tk_bin(unsigned int key) {       // monotone in the key; sigmoid <= 1.0 -> bin <= 4064, NaN patterns clamp to the top
+    const unsigned int b = key >> TK_SH;
+    return b > (unsigned int)(TK_NB - 1) ? TK_NB - 1 : (int)b;
+}
+__global__ __launch_bounds__(1024) void topk_scan_kernel(ScanBatch b) {
+    const ScanArgs &a = b.p[blockIdx.z];
+    const int g = (int)blockIdx.x, cls = (int)blockIdx.y;
+    if (cls >= a.nclass || g >= a.G) return;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per_wave = a.chunk >> 4;                       // multiple of 64
+    const int beg = g * a.chunk + w * per_wave, end = min(a.L, beg + per_wave);
+    const float *col = a.hm + cls;
+    const bool all_pass = a.score_thresh < 0.f;
+    const unsigned int tkey = __float_as_uint(a.score_thresh);
+    __shared__ int s_wcnt[16];
+    __shared__ int s_hist[TK_NB];
+    unsigned int kv[4];
+    float v[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = beg + it * 64 + lane;
+        v[it] = (it * 64 < per_wave && i < end) ? col[(size_t)i * a.hm_ld] : 0.f;
+    }
+    for (int i = threadIdx.x; i < TK_NB; i += 1024) s_hist[i] = 0;
+    __syncthreads();
+    int cnt = 0;
+    u64 pm[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = beg + it * 64 + lane;
+        const bool in = it * 64 < per_wave && i < end;
+        kv[it] = in ? __float_as_uint(sigmoidf_dev(v[it])) : 0u;
+        if (in) a.keys_all[(size_t)cls * a.L + i] = kv[it];
+        const bool pass_ = in && (all_pass || kv[it] > tkey);
+        pm[it] = __ballot(pass_);
+        if (pass_) atomicAdd(&s_hist[tk_bin(kv[it])], 1);
+        cnt += (int)__popcll(pm[it]);
+    }
+    if (lane == 0) s_wcnt[w] = cnt;
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int q = 0; q < 16; ++q) { base += q < w ? s_wcnt[q] : 0; total += s_wcnt[q]; }
+    const size_t cbase = ((size_t)cls * a.G + g) * a.chunk;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if ((pm[it] >> lane) & 1ull) {
+            const int pos = base + (int)__popcll(pm[it] & ((1ull << lane) - 1ull));
+            a.cand[cbase + pos] = ((u64)kv[it] << 32) | (u64)(0xffffffffu - (unsigned int)(beg + it * 64 + lane));
+        }
+        base += (int)__popcll(pm[it]);
+    }
+    if (threadIdx.x == 0) a.chunk_cnt[cls * a.G + g] = total;
+    int *hdst = a.chunk_hist + ((size_t)cls * a.G + g) * TK_NB;
+    for (int i = threadIdx.x; i < TK_NB; i += 1024) hdst[i] = s_hist[i];
+}
+
+__global__ __launch_bounds__(1024) void topk_select_kernel(ScanBatch b) {
+    const ScanArgs &a = b.p[blockIdx.y];
+    const int cls = (int)blockIdx.x;
+    if (cls >= a.nclass) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u64 *sel = reinterpret_cast<u64 *>(smem_raw);          // [Kpad]
+    int *hist = reinterpret_cast<int *>(sel + a.Kpad);     // [TK_NB]
+    u64 *sortbuf = reinterpret_cast<u64 *>(hist + TK_NB);  // [TK_SORT]
+    // the general select (crowded pivot bin) needs hist[256] + sh[16] and all L keys: they take over the space from hist + 272 on
+    unsigned int *keys_s = reinterpret_cast<unsigned int *>(hist + 272);
+    unsigned int *idx_s = keys_s;                           // unused by the unfiltered select
+    __shared__ int s_base[TK_MAXG + 1], s_piv, s_rem, s_fill, s_surv, s_sh[16];
+    const int tid = threadIdx.x, G = a.G, K = a.K;
+    DN_STAMP(0, 0);
+    {       // exclusive prefix of the chunk counts: lanes 0..16 of wave 0, one load each
+        const int lane = tid & 63;
+        if (tid < 64) {
+            const int c = lane < G ? a.chunk_cnt[cls * G + lane] : 0;
+            int incl = c;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const int t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            if (lane <= TK_MAXG) s_base[lane] = incl - c;
+        }
+        if (tid == 0) { s_piv = -1; s_rem = 0; s_fill = 0; s_surv = 0; }
+    }
+    // 1. histogram of all candidates of the class
+    {
+        int h[TK_NB / 1024];
+#pragma unroll
+        for (int u = 0; u < TK_NB / 1024; ++u) h[u] = 0;
+        const int *src = a.chunk_hist + (size_t)cls * G * TK_NB;
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int u = 0; u < TK_NB / 1024; ++u) h[u] += src[(size_t)g * TK_NB + u * 1024 + tid];
+#pragma unroll
+        for (int u = 0; u < TK_NB / 1024; ++u) hist[u * 1024 + tid] = h[u];
+    }
+    for (int i = tid; i < a.Kpad; i += 1024) sel[i] = 0ull;
+    __syncthreads();
+    DN_STAMP(0, 1);
+    const int n = s_base[TK_MAXG];
+    const int Keff = K < n ? K : n;
+    if (Keff == 0) {        // nothing above the threshold
+        for (int i = tid; i < K; i += 1024) a.out[(size_t)cls * K + i] = 0ull;
+        return;
+    }
+    // 2. the bin of the Keff-th largest key: thread t owns the bins TK_NB-1-4t .. TK_NB-4-4t (descending), block prefix from the top
+    {
+        constexpr int PER = TK_NB / 1024;
+        int h[PER], local = 0;
+#pragma unroll
+        for (int u = 0; u < PER; ++u) { h[u] = hist[TK_NB - 1 - (tid * PER + u)]; local += h[u]; }
+        int tot;
+        int above = block_scan_excl_1024(local, s_sh, &tot);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (above < Keff && above + h[u] >= Keff) { s_piv = TK_NB - 1 - (tid * PER + u); s_rem = Keff - above; }     // exactly one (thread, u)
+            above += h[u];
+        }
+    }
+    __syncthreads();
+    const int piv = s_piv, rem = s_rem, m = hist[piv], pre = Keff - rem;
+    DN_STAMP(0, 2);
+    if (m > TK_SORT) {
+        // crowded pivot bin: the general select over every pixel's key (keys_all -> LDS), ties by pixel order
+        __syncthreads();        // hist[piv] read by everyone before the select reuses hist
+        const int L = a.L;
+        const unsigned int *src = a.keys_all + (size_t)cls * L;
+        for (int base = tid; base < L; base += 8 * 1024) {
+            unsigned int t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = base + u * 1024 < L ? src[base + u * 1024] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base + u * 1024 < L) keys_s[base + u * 1024] = t[u];
+        }
+        topk_select_tail(a.hm + cls, a.hm_ld, L, false, 1, K, a.Kpad, sel, hist, hist + 256, keys_s, idx_s, a.out, cls);
+        return;
+    }
+    // 3. one pass over the candidates: higher bin -> selected, pivot bin -> composite into the sort buffer
+    for (int i = tid; i < TK_SORT; i += 1024) sortbuf[i] = 0ull;
+    __syncthreads();
+    DN_STAMP(0, 3);
+    // chunk-major, three chunks (12 eight-byte loads per thread) per round trip; the chunk counts sit in registers (static indices)
+    {
+        int cntg[TK_MAXG];
+#pragma unroll
+        for (int g = 0; g < TK_MAXG; ++g) cntg[g] = s_base[g + 1] - s_base[g];
+#pragma unroll
+        for (int r = 0; r < (TK_MAXG + 2) / 3; ++r) {
+            if (r * 3 >= G) break;
+            u64 cc[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int g = r * 3 + u / 4, j = tid + (u & 3) * 1024;
+                cc[u] = (g < TK_MAXG && j < cntg[g < TK_MAXG ? g : 0]) ? a.cand[((size_t)cls * G + g) * a.chunk + j] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                if (cc[u] == 0ull) continue;        // a candidate's composite is never 0 (its low word is ~pixel)
+                const int bin = tk_bin((unsigned int)(cc[u] >> 32));
+                if (bin > piv) sel[atomicAdd(&s_fill, 1)] = cc[u];
+                else if (bin == piv) sortbuf[atomicAdd(&s_surv, 1)] = cc[u];
+            }
+        }
+    }
+    __syncthreads();
+    DN_STAMP(0, 4);
+    // 4. the pivot bin's keys, best first ((score, ~pixel) composites: equal scores order by ascending pixel): the first `rem` go in
+    if (m <= 512) {         // the usual case: rank by counting (m broadcast reads per key) instead of a 45-stage bitonic network
+        if (tid < m) {
+            const u64 mine = sortbuf[tid];
+            int rank = 0;
+            for (int j0 = 0; j0 < m; j0 += 8) {         // slots beyond m hold 0 (never greater); 8 broadcast reads in flight
+                u64 o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = sortbuf[j0 + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) rank += o[u] > mine ? 1 : 0;      // composites are distinct
+            }
+            if (rank < rem) sel[pre + rank] = mine;
+        }
+    } else {
+        int npad = 1024;
+        while (npad < m) npad <<= 1;
+        bitonic_sort_desc_hybrid(sortbuf, npad);
+        for (int i = tid; i < rem; i += 1024) sel[pre + i] = sortbuf[i];
+    }
+    __syncthreads();
+    DN_STAMP(0, 5);
+    for (int i = tid; i < K; i += 1024) a.out[(size_t)cls * K + i] = (i < Keff) ? sel[i] : 0ull;
+    DN_STAMP(0, 6);
+}
+
 // ------------------------------------------------------------------ stage 2: top-K over classes*K, decode, mask
 struct DecodeParams {
     aq3d_decode_cfg c;
@@ -354,6 +596,7 @@ __device__ __forceinline__ void decode_body(const u64 *__restrict__ cand, int nc
     u64 *keys = reinterpret_cast<u64 *>(smem_raw);  // [Npad] : score bits << 32 | ~position (position = class*K + rank)
     __shared__ int sh[16];
     const int K = q.c.K;
+    DN_STAMP(1, 0);
     for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
         u64 v = 0ull;
         if (i < ncand) {
@@ -367,8 +610,10 @@ __device__ __forceinline__ void decode_body(const u64 *__restrict__ cand, int nc
         keys[i] = v;
     }
     __syncthreads();
+    DN_STAMP(1, 1);
     if (Npad >= 128 && Npad <= 2048 && blockDim.x == 1024) bitonic_sort_desc_hybrid(keys, Npad);
     else bitonic_sort_desc(keys, Npad);
+    DN_STAMP(1, 2);
 
     const int nbox = q.c.has_vel ? 9 : 7;
     const int t = threadIdx.x;
@@ -404,14 +649,17 @@ __device__ __forceinline__ void decode_body(const u64 *__restrict__ cand, int nc
         for (int j = 0; j < 3; ++j) valid &= (box[j] >= q.c.post_center_range[j]) && (box[j] <= q.c.post_center_range[3 + j]);
         if (q.c.score_thresh >= 0.f) valid &= score > q.c.score_thresh;
     }
+    DN_STAMP(1, 3);
     int total;
     const int dst = block_scan_excl_1024(valid, sh, &total);
+    DN_STAMP(1, 4);
     if (valid) {
         for (int j = 0; j < nbox; ++j) boxes_out[(size_t)dst * nbox + j] = box[j];
         scores_out[dst] = score;
         labels_out[dst] = label;
     }
     if (threadIdx.x == 0) *count_out = total;
+    DN_STAMP(1, 5);
 }
 
 struct DecodeArgs {
@@ -431,9 +679,32 @@ __global__ __launch_bounds__(1024) void decode_kernel(DecodeBatch b) {
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
+// workspace: [classes][K] selected keys | (dense maps whose keys fit LDS) keys_all | cand | chunk_cnt | chunk_hist
+struct TopkWs { size_t sel, keys_all, cand, chunk_cnt, chunk_hist; int G, chunk, multi; };
+static size_t topk_ws_layout(const aq3d_decode_cfg *cfg, TopkWs *w) {
+    TopkWs t;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    t.sel = take((size_t)cfg->num_classes * cfg->K * sizeof(u64) + 256);
+    const long L = (long)cfg->H * cfg->W;
+    t.multi = (L > 0 && L * 4 <= 141 * 1024) ? 1 : 0;          // the same bound as cache_keys below
+    t.G = t.chunk = 0;
+    t.keys_all = t.cand = t.chunk_cnt = t.chunk_hist = 0;
+    if (t.multi) {
+        t.G = (int)((L + 4095) / 4096);
+        t.chunk = (int)(((L + t.G - 1) / t.G + 1023) / 1024 * 1024);
+        t.keys_all = take((size_t)cfg->num_classes * L * 4);
+        t.cand = take((size_t)cfg->num_classes * t.G * t.chunk * 8);
+        t.chunk_cnt = take((size_t)cfg->num_classes * t.G * 4);
+        t.chunk_hist = take((size_t)cfg->num_classes * t.G * TK_NB * 4);
+    }
+    if (w) *w = t;
+    return off;
+}
+
 extern "C" size_t aq3d_center_decode_workspace_bytes(const aq3d_decode_cfg *cfg) {
     if (!cfg) return 0;
-    return (size_t)cfg->num_classes * cfg->K * sizeof(u64) + 256;
+    return topk_ws_layout(cfg, nullptr);
 }
 
 // One decode problem: dense maps (coords == NULL: aq3d_center_decode) or rows of a sparse head (aq3d_voxel_decode).
@@ -466,9 +737,23 @@ static int check_decode(const DecodeProblem &d, const char *who) {
 // top-K per class + decode of n <= AQ3D_MAX_HEADS checked problems: two launches
 static void launch_decode(const DecodeProblem *d, int n, hipStream_t stream) {
     TopkBatch tb;
+    ScanBatch sb;
     DecodeBatch db;
     size_t lds1_max = 0, lds2_max = 0;
-    int max_classes = 1;
+    int max_classes = 1, max_g = 1;
+    bool multi = true;          // dense maps whose key cache fits LDS: scores evaluated by many workgroups (topk_scan_kernel)
+    for (int i = 0; i < n; ++i) {
+        TopkWs w;
+        topk_ws_layout(d[i].cfg, &w);
+        multi = multi && !d[i].coords && w.multi;
+        ScanArgs &c = sb.p[i];
+        char *ws = (char *)d[i].workspace;
+        c.hm = d[i].hm; c.hm_ld = d[i].cfg->hm_ld; c.L = d[i].cfg->H * d[i].cfg->W; c.nclass = d[i].cfg->num_classes; c.G = w.G; c.chunk = w.chunk;
+        c.K = d[i].cfg->K; c.Kpad = next_pow2(c.K); c.score_thresh = d[i].cfg->score_thresh;
+        c.keys_all = (unsigned int *)(ws + w.keys_all); c.cand = (u64 *)(ws + w.cand);
+        c.chunk_cnt = (int *)(ws + w.chunk_cnt); c.chunk_hist = (int *)(ws + w.chunk_hist); c.out = (u64 *)(ws + w.sel);
+        max_g = w.G > max_g ? w.G : max_g;
+    }
     for (int i = 0; i < n; ++i) {
         const aq3d_decode_cfg *cfg = d[i].cfg;
         const int L = d[i].coords ? d[i].cap : cfg->H * cfg->W, K = cfg->K, Kpad = next_pow2(K);
@@ -491,10 +776,23 @@ static void launch_decode(const DecodeProblem *d, int n, hipStream_t stream) {
         lds2_max = lds2 > lds2_max ? lds2 : lds2_max;
         max_classes = cfg->num_classes > max_classes ? cfg->num_classes : max_classes;
     }
-    for (int i = n; i < AQ3D_MAX_HEADS; ++i) { tb.p[i] = tb.p[0]; db.p[i] = db.p[0]; }
-    if (lds1_max > 64 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void *>(topk_per_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1_max);
-    hipLaunchKernelGGL(topk_per_class_kernel, dim3(max_classes, n), dim3(1024), lds1_max, stream, tb);
+    for (int i = n; i < AQ3D_MAX_HEADS; ++i) { tb.p[i] = tb.p[0]; db.p[i] = db.p[0]; sb.p[i] = sb.p[0]; }
+    if (multi) {
+        size_t lds_sel = 0;
+        for (int i = 0; i < n; ++i) {
+            const size_t a_ = (size_t)TK_NB * 4 + (size_t)TK_SORT * 8, b_ = 272 * 4 + (size_t)sb.p[i].L * 4;
+            const size_t l = (size_t)sb.p[i].Kpad * 8 + (a_ > b_ ? a_ : b_);
+            lds_sel = l > lds_sel ? l : lds_sel;
+        }
+        hipLaunchKernelGGL(topk_scan_kernel, dim3(max_g, max_classes, n), dim3(1024), 0, stream, sb);
+        if (lds_sel > 64 * 1024)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(topk_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sel);
+        hipLaunchKernelGGL(topk_select_kernel, dim3(max_classes, n), dim3(1024), lds_sel, stream, sb);
+    } else {
+        if (lds1_max > 64 * 1024)
+            hipFuncSetAttribute(reinterpret_cast<const void *>(topk_per_class_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1_max);
+        hipLaunchKernelGGL(topk_per_class_kernel, dim3(max_classes, n), dim3(1024), lds1_max, stream, tb);
+    }
     if (lds2_max > 64 * 1024)
         hipFuncSetAttribute(reinterpret_cast<const void *>(decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2_max);
     hipLaunchKernelGGL(decode_kernel, dim3(n), dim3(1024), lds2_max, stream, db);
@@ -580,18 +878,29 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(NmsBatch nb_) {
     int *__restrict__ keep = q.keep, *__restrict__ keep_count = q.keep_count;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u64 *mask_s = reinterpret_cast<u64 *>(smem_raw);
+    DN_STAMP(2, 0);
     int n = *count;
     if (n > cap) n = cap;
     const u64 *msrc = mask;
+    DN_STAMP(2, 1);
     if (use_lds) {
         const int words = n * col_blocks;
-        for (int i = threadIdx.x; i < words; i += blockDim.x) mask_s[i] = mask[i];
+        for (int i0 = threadIdx.x; i0 < words; i0 += 8 * 256) {      // 8 independent loads per thread and round trip (blockDim.x == 256)
+            u64 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = i0 + u * 256 < words ? mask[i0 + u * 256] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * 256 < words) mask_s[i0 + u * 256] = t[u];
+        }
         __syncthreads();
         msrc = mask_s;
     }
+    DN_STAMP(2, 2);
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
-    u64 remv = 0ull;
+    __shared__ u64 remv_s[64];          // removal word per column block (cap <= 4096)
+    remv_s[lane] = 0ull;
     int num = 0;
     const int nb = (n + 63) >> 6;
     for (int b = 0; b < nb; ++b) {
@@ -604,29 +913,42 @@ __global__ __launch_bounds__(256) void nms_sweep_kernel(NmsBatch nb_) {
             const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
             return ((u64)hi << 32) | lo;
         };
-        u64 cur = bcast(remv, b);
-        u64 kept = 0ull;
-        const int lim = min(64, n - b * 64);
-        for (int t = 0; t < lim; ++t) {
-            const u64 d = bcast(diag, t);
-            const bool take = !((cur >> t) & 1ull);
-            if (take) { kept |= 1ull << t; cur |= d; }
+        // Greedy pass over the block: box t is kept iff bit t of `cur` is clear when t is visited, and a kept box ORs in its diagonal
+        // word (bits above t only). Boxes whose diagonal word is empty never change `cur`, so only the others are visited, in order
+        // (s_ff1 over their ballot): after the walk kept = ~cur. (64 unconditional steps cost 2.2 us per block on the scalar unit —
+        // ~85 cycles per step for a lone wave — whether or not anything overlapped.)
+        u64 cur = remv_s[b];
+        cur = bcast(cur, 0);
+        u64 todo = __ballot(diag != 0ull);
+        while (todo) {
+            const int t = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            if (!((cur >> t) & 1ull)) cur |= bcast(diag, t);
         }
+        const int lim = min(64, n - b * 64);
+        u64 kept = ~cur;
+        if (lim < 64) kept &= (1ull << lim) - 1ull;
+        if (b == 0) DN_STAMP(2, 3);
         if ((kept >> lane) & 1ull) {
             const int pos = num + __popcll(kept & ((1ull << lane) - 1ull));
             if (pos < post_max) keep[pos] = row;
         }
         num += __popcll(kept);
-        if (lane > b && lane < col_blocks) {
-#pragma unroll 8
-            for (int t = 0; t < 64; ++t) {
-                const int r = b * 64 + t;
-                const u64 m = (r < n) ? msrc[(size_t)r * col_blocks + lane] : 0ull;
-                if ((kept >> t) & 1ull) remv |= m;
+        if (b == 0) DN_STAMP(2, 4);
+        if (b + 1 >= nb) break;          // nothing behind the last block
+        // remv[c] |= OR of the kept rows' words of column block c, for c > b: lane = one kept row, LDS OR-atomics into the removal words
+        // (the wave's LDS operations complete in order: the next block's read of remv_s sees them)
+        if ((kept >> lane) & 1ull) {
+            for (int c = b + 1; c < col_blocks; ++c) {
+                const u64 mw = msrc[(size_t)row * col_blocks + c];
+                if (mw) atomicOr(reinterpret_cast<unsigned long long *>(&remv_s[c]), mw);
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (b == 0) DN_STAMP(2, 5);
     }
     if (lane == 0) *keep_count = num < post_max ? num : post_max;
+    DN_STAMP(2, 6);
 }
 
 extern "C" size_t aq3d_nms_workspace_bytes(int32_t cap) {

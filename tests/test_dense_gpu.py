@@ -169,6 +169,42 @@ def test_center_decode(dev, H, W, ncls, K):
     np.testing.assert_allclose(boxes[:n].cpu().numpy(), b_ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("kind,H,W,ncls,K", [("hover", 188, 188, 3, 500), ("constant", 188, 188, 3, 500), ("constant", 100, 100, 2, 500),
+                                              ("steps", 100, 100, 3, 100), ("steps10", 100, 100, 2, 100), ("hover", 180, 180, 2, 83)])
+def test_center_decode_crowded_and_tied_maps(dev, kind, H, W, ncls, K):
+    """The top-K beyond the few-peaks case: more scores above the threshold than the candidate cache holds (the select then runs
+    over every pixel's key), and maps full of equal scores (the K winners are the smallest pixel indices, across the chunks the
+    score pass is split into) — random-weight heads produce the first, a saturated head the second."""
+    from amdq3d import ops
+    rng = np.random.default_rng(H + K + len(kind))
+    hm, center, center_z, dim, rot = _head_maps(H, W, ncls, seed=H + K, peaks=0)
+    if kind == "hover":
+        hm = rng.normal(-2.19, 0.5, (ncls, H, W)).astype(np.float32)
+    elif kind == "constant":
+        hm = np.full((ncls, H, W), -1.0, np.float32)
+    elif kind == "steps10":     # ten levels, ~1000 pixels each: the K-th score's histogram bin holds more keys than the rank-by-counting path takes
+        hm = (rng.integers(0, 10, (ncls, H, W)) * 0.3 - 2.0).astype(np.float32)
+    else:       # a handful of distinct levels: thousands of ties at the K-th score
+        hm = rng.integers(-3, 2, (ncls, H, W)).astype(np.float32)
+    pc_range = [-75.2, -75.2, -2.0, 75.2, 75.2, 4.0]
+    b_ref, s_ref, l_ref = OD.decode_bbox_from_heatmap(OD.sigmoid(hm), center, center_z, np.exp(dim), rot, None, pc_range,
+                                                      [0.1, 0.1, 0.15], 8, K, 0.1, pc_range)
+    buf = np.zeros((H * W, 24), np.float32)
+    buf[:, 0:ncls] = hm.reshape(ncls, -1).T
+    buf[:, 4:6] = center.reshape(2, -1).T
+    buf[:, 6:7] = center_z.reshape(1, -1).T
+    buf[:, 8:11] = dim.reshape(3, -1).T
+    buf[:, 12:14] = rot.reshape(2, -1).T
+    t = torch.from_numpy(buf).to(dev)
+    cfg = ops.make_decode_cfg(H, W, ncls, K, False, 8, [0.1, 0.1], pc_range, pc_range, 0.1, 24, 24)
+    boxes, scores, labels, count = ops.center_decode(t, t[:, 4:], t[:, 6:], t[:, 8:], t[:, 12:], None, cfg)
+    n = int(count.item())
+    assert n == len(s_ref) and n > 0
+    np.testing.assert_array_equal(labels[:n].cpu().numpy(), l_ref)
+    np.testing.assert_allclose(scores[:n].cpu().numpy(), s_ref, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(boxes[:n].cpu().numpy(), b_ref, rtol=1e-5, atol=1e-5)
+
+
 def _boxes(n, seed):
     rng = np.random.default_rng(seed)
     ctr = rng.uniform(-30, 30, (max(n // 6, 1), 2))
