@@ -208,6 +208,8 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
         const int toff = (ls_kh * a.W + ls_kw) * a.in_ld + c0;      // wave-uniform
         if (++ls_kw == a.ks) { ls_kw = 0; ++ls_kh; }
         if (++ls_tap == ntaps) { ls_tap = 0; ls_kh = 0; ls_kw = 0; ls_c0 += 64; }
+        // (measured round 3: fetching s | 1/s with lanes 0-15 only and handing them to the other three pixel groups of the wave by
+        // ds_bpermute — a quarter of the vector-memory bytes of these two loads — is 4-11 % SLOWER: the loads hit L1, the shuffles wait)
         const unsigned col = (unsigned)(tap * a.Cin + c0 + cq * 4) * 4u;
         st.sr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, col, 0, 0));
         st.rr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, col, 0, 0));
