@@ -372,7 +372,11 @@ typedef struct {
     int32_t hm_ld, reg_ld;     /* pixel strides (floats) of the heat map and of the regression maps */
 } aq3d_decode_cfg;
 
+/* Workspace of the decode calls. The returned size lets the top-K run on many workgroups (score pass + histogram select) when the map
+ * (H*W pixels) or the sparse head's row capacity is at most 36 096 entries; num_classes * K * 8 + 256 bytes is the minimum either call
+ * accepts (one workgroup per class then). Contents are scratch: nothing has to be initialised or preserved between calls. */
 size_t aq3d_center_decode_workspace_bytes(const aq3d_decode_cfg *cfg);
+size_t aq3d_voxel_decode_workspace_bytes(const aq3d_decode_cfg *cfg, int32_t cap);
 
 /* Raw head outputs (NHWC f32, pre-sigmoid heat map; dim pre-exp) → candidate boxes sorted by score (desc,
  * ties by class-major flat index asc) with the range / score mask applied:
@@ -408,7 +412,7 @@ typedef struct aq3d_head_problem {
     float *cand_boxes, *cand_scores;                           /* [K, 7 or 9], [K]                          */
     int32_t *cand_labels, *cand_count;                         /* [K], [1]                                  */
     void *decode_workspace;
-    size_t decode_workspace_bytes;                             /* aq3d_center_decode_workspace_bytes(cfg)   */
+    size_t decode_workspace_bytes;                             /* aq3d_center_ / aq3d_voxel_decode_workspace_bytes */
     float nms_thresh;
     int32_t nms_cap, post_max;
     int32_t *keep, *keep_count;                                /* [nms_cap], [1]                            */

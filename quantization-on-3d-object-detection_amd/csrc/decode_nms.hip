@@ -378,7 +378,8 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(TopkBatch b) {
 // No cross-workgroup hand-off inside a launch: the kernel boundary is the synchronisation.
 struct ScanArgs {
     const float *hm;
-    int hm_ld, L, nclass, G, chunk, K, Kpad;
+    const int *count;                                   // sparse head: live rows on the device (<= L); NULL for a dense map
+    int hm_ld, L, nclass, G, chunk, K, Kpad;            // L: H*W, or the row capacity of a sparse head
     float score_thresh;
     unsigned int *keys_all;                             // [nclass][L]
     u64 *cand;                                          // [nclass][G*chunk] composites: score bits << 32 | ~pixel
@@ -399,7 +400,9 @@ __global__ __launch_bounds__(1024) void topk_scan_kernel(ScanBatch b) {
     if (cls >= a.nclass || g >= a.G) return;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int per_wave = a.chunk >> 4;                       // multiple of 64
-    const int beg = g * a.chunk + w * per_wave, end = min(a.L, beg + per_wave);
+    int L = a.L;
+    if (a.count) { L = *a.count; L = L < 0 ? 0 : (L > a.L ? a.L : L); }
+    const int beg = g * a.chunk + w * per_wave, end = min(L, beg + per_wave);
     const float *col = a.hm + cls;
     const bool all_pass = a.score_thresh < 0.f;
     const unsigned int tkey = __float_as_uint(a.score_thresh);
@@ -514,8 +517,9 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(ScanBatch b) {
     if (m > TK_SORT) {
         // crowded pivot bin: the general select over every pixel's key (keys_all -> LDS), ties by pixel order
         __syncthreads();        // hist[piv] read by everyone before the select reuses hist
-        const int L = a.L;
-        const unsigned int *src = a.keys_all + (size_t)cls * L;
+        int L = a.L;
+        if (a.count) { L = *a.count; L = L < 0 ? 0 : (L > a.L ? a.L : L); }
+        const unsigned int *src = a.keys_all + (size_t)cls * a.L;
         for (int base = tid; base < L; base += 8 * 1024) {
             unsigned int t[8];
 #pragma unroll
@@ -681,12 +685,11 @@ static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 // workspace: [classes][K] selected keys | (dense maps whose keys fit LDS) keys_all | cand | chunk_cnt | chunk_hist
 struct TopkWs { size_t sel, keys_all, cand, chunk_cnt, chunk_hist; int G, chunk, multi; };
-static size_t topk_ws_layout(const aq3d_decode_cfg *cfg, TopkWs *w) {
+static size_t topk_ws_layout(const aq3d_decode_cfg *cfg, long L, TopkWs *w) {     // L: pixels of the map / row capacity of the sparse head
     TopkWs t;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     t.sel = take((size_t)cfg->num_classes * cfg->K * sizeof(u64) + 256);
-    const long L = (long)cfg->H * cfg->W;
     t.multi = (L > 0 && L * 4 <= 141 * 1024) ? 1 : 0;          // the same bound as cache_keys below
     t.G = t.chunk = 0;
     t.keys_all = t.cand = t.chunk_cnt = t.chunk_hist = 0;
@@ -704,8 +707,14 @@ static size_t topk_ws_layout(const aq3d_decode_cfg *cfg, TopkWs *w) {
 
 extern "C" size_t aq3d_center_decode_workspace_bytes(const aq3d_decode_cfg *cfg) {
     if (!cfg) return 0;
-    return topk_ws_layout(cfg, nullptr);
+    return topk_ws_layout(cfg, (long)cfg->H * cfg->W, nullptr);
 }
+
+extern "C" size_t aq3d_voxel_decode_workspace_bytes(const aq3d_decode_cfg *cfg, int32_t cap) {
+    if (!cfg) return 0;
+    return topk_ws_layout(cfg, cap, nullptr);
+}
+static size_t decode_ws_min(const aq3d_decode_cfg *cfg) { return (size_t)cfg->num_classes * cfg->K * sizeof(u64) + 256; }
 
 // One decode problem: dense maps (coords == NULL: aq3d_center_decode) or rows of a sparse head (aq3d_voxel_decode).
 struct DecodeProblem {
@@ -727,7 +736,7 @@ static int check_decode(const DecodeProblem &d, const char *who) {
     AQ3D_REQUIRE(d.cfg->K >= 1 && d.cfg->K <= 512, "%s: K=%d not in 1..512", who, d.cfg->K);
     if (d.coords) AQ3D_REQUIRE(d.count && d.cap >= 1, "%s: sparse head without count / cap=%d", who, d.cap);
     else AQ3D_REQUIRE(d.cfg->H > 0 && d.cfg->W > 0, "%s: empty map", who);
-    if (d.workspace_bytes < aq3d_center_decode_workspace_bytes(d.cfg)) {
+    if (d.workspace_bytes < decode_ws_min(d.cfg)) {     // the full *_workspace_bytes() size enables the multi-workgroup top-K, this much is required
         aq3d_set_error("%s: workspace too small", who);
         return AQ3D_ERR_WORKSPACE;
     }
@@ -741,14 +750,15 @@ static void launch_decode(const DecodeProblem *d, int n, hipStream_t stream) {
     DecodeBatch db;
     size_t lds1_max = 0, lds2_max = 0;
     int max_classes = 1, max_g = 1;
-    bool multi = true;          // dense maps whose key cache fits LDS: scores evaluated by many workgroups (topk_scan_kernel)
+    bool multi = true;          // maps / row sets whose key cache fits LDS and whose workspace has room: scores evaluated by many workgroups
     for (int i = 0; i < n; ++i) {
         TopkWs w;
-        topk_ws_layout(d[i].cfg, &w);
-        multi = multi && !d[i].coords && w.multi;
+        const long Ls = d[i].coords ? (long)d[i].cap : (long)d[i].cfg->H * d[i].cfg->W;
+        const size_t need = topk_ws_layout(d[i].cfg, Ls, &w);
+        multi = multi && w.multi && d[i].workspace_bytes >= need;
         ScanArgs &c = sb.p[i];
         char *ws = (char *)d[i].workspace;
-        c.hm = d[i].hm; c.hm_ld = d[i].cfg->hm_ld; c.L = d[i].cfg->H * d[i].cfg->W; c.nclass = d[i].cfg->num_classes; c.G = w.G; c.chunk = w.chunk;
+        c.hm = d[i].hm; c.count = d[i].coords ? d[i].count : nullptr; c.hm_ld = d[i].cfg->hm_ld; c.L = (int)Ls; c.nclass = d[i].cfg->num_classes; c.G = w.G; c.chunk = w.chunk;
         c.K = d[i].cfg->K; c.Kpad = next_pow2(c.K); c.score_thresh = d[i].cfg->score_thresh;
         c.keys_all = (unsigned int *)(ws + w.keys_all); c.cand = (u64 *)(ws + w.cand);
         c.chunk_cnt = (int *)(ws + w.chunk_cnt); c.chunk_hist = (int *)(ws + w.chunk_hist); c.out = (u64 *)(ws + w.sel);

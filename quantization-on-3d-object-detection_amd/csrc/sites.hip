@@ -103,7 +103,7 @@ __device__ __forceinline__ int lv_find(const Lv &L, int b, int z, int y, int x) 
     const int bit = ((y & 7) << 3) | (x & 7);
     const int rank = base + __popcll(bits & ((1ull << bit) - 1ull));
     const bool hit = in && ((bits >> bit) & 1ull) && rank < L.cap;
-    const int row = L.rank2row[hit ? rank : 0];
+    const int row = L.sorted ? L.rank2row[hit ? rank : 0] : rank;      // raster-ordered levels: row == rank (one dependent load less)
     return hit ? row : -1;
 }
 
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_neighbors(Lv Out, NbrJobs J, int 
 #define IX_SEL(f) (ji == 0 ? J.j[0].f : (ji == 1 ? J.j[1].f : (ji == 2 ? J.j[2].f : J.j[3].f)))
     Lv In;
     In.Z = IX_SEL(In.Z); In.Y = IX_SEL(In.Y); In.X = IX_SEL(In.X); In.B = IX_SEL(In.B); In.cap = IX_SEL(In.cap);
-    In.PY = IX_SEL(In.PY); In.PX = IX_SEL(In.PX); In.words = 0;
+    In.PY = IX_SEL(In.PY); In.PX = IX_SEL(In.PX); In.words = 0; In.sorted = IX_SEL(In.sorted);
     In.bits = IX_SEL(In.bits); In.base = IX_SEL(In.base); In.rank2row = IX_SEL(In.rank2row);
     In.coords = nullptr; In.count = nullptr; In.total = nullptr;
     Geo g;
@@ -713,7 +713,7 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_link(int n, Lv L, IxWs ws) {
         const int w = cell >> 6, bit = cell & 63;
         const int rank = L.base[w] + __popcll(L.bits[w] & ((1ull << bit) - 1ull));
         if (rank >= L.cap) continue;
-        const int row = L.rank2row[rank];
+        const int row = L.sorted ? L.rank2row[rank] : rank;
         ws.next[i] = atomicExch(&ws.head[row], i);
     }
 }

@@ -449,7 +449,7 @@ class Engine:
                        out_boxes=torch.zeros((self.NSLOT, B, K, nb), dtype=f32, device=dev),
                        out_scores=torch.zeros((self.NSLOT, B, K), dtype=f32, device=dev),
                        out_labels=torch.zeros((self.NSLOT, B, K), dtype=torch.int64, device=dev),
-                       dec_ws=torch.empty((max(L.aq3d_center_decode_workspace_bytes(ctypes.byref(cfg)), 256),),
+                       dec_ws=torch.empty((max(L.aq3d_voxel_decode_workspace_bytes(ctypes.byref(cfg), self.levels[oi]["cap"]), 256),),
                                           dtype=torch.uint8, device=dev),
                        nms_ws=torch.empty((max(L.aq3d_nms_workspace_bytes(K), 256),), dtype=torch.uint8, device=dev))
             self.heads.append(rec)

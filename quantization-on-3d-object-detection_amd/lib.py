@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class Aq3dError(RuntimeError):
@@ -114,6 +114,7 @@ SIGNATURES = {
     "aq3d_conv2d_sq16_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "aq3d_conv2d_sq16": (c_int32, [P, P, POINTER(Conv2dGeom), c_int32, c_int32, P, P, P, P, P, c_size_t, P]),
     "aq3d_center_decode_workspace_bytes": (c_size_t, [POINTER(DecodeCfg)]),
+    "aq3d_voxel_decode_workspace_bytes": (c_size_t, [POINTER(DecodeCfg), c_int32]),
     "aq3d_center_decode": (c_int32, [P, P, P, P, P, P, POINTER(DecodeCfg), P, P, P, P, P, c_size_t, P]),
     "aq3d_nms_workspace_bytes": (c_size_t, [c_int32]),
     "aq3d_nms_rotated": (c_int32, [P, c_int32, P, c_int32, c_float, c_int32, P, P, P, c_size_t, P]),

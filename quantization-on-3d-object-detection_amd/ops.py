@@ -533,10 +533,10 @@ def voxel_decode(hm, center, center_z, dim, rot, vel, coords, count, cfg, worksp
         cnt = torch.zeros((1,), dtype=i32, device=dev)
     else:
         boxes, scores, labels, cnt = out
-    need = L.aq3d_center_decode_workspace_bytes(ctypes.byref(cfg))
+    cap = coords.shape[0]
+    need = L.aq3d_voxel_decode_workspace_bytes(ctypes.byref(cfg), cap)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
-    cap = coords.shape[0]
     assert hm.shape[0] >= cap and hm.stride(0) == cfg.hm_ld and center.stride(0) == cfg.reg_ld
     check(L.aq3d_voxel_decode(_pv(hm), _pv(center), _pv(center_z), _pv(dim), _pv(rot), _pv(vel), _p(coords), _p(count), cap,
                               ctypes.byref(cfg), _p(boxes), _p(scores), _p(labels), _p(cnt), _p(workspace), workspace.numel(),
