@@ -77,35 +77,29 @@ __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
     const unsigned lo = __shfl_xor((unsigned)v, m, 64), hi = __shfl_xor((unsigned)(v >> 32), m, 64);
     return ((u64)hi << 32) | lo;
 }
-__device__ __forceinline__ void bitonic_sort_desc_hybrid(u64 *keys, int n) {       // n: power of two, 128 <= n <= 128 * waves
+__device__ __forceinline__ void bitonic_sort_desc_hybrid(u64 *keys, int n) {       // n: power of two, 128 <= n <= 128 * waves (<= 2048)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int base = wave * 128;
     const bool active = base < n;
     u64 e0 = active ? keys[base + lane] : 0ull, e1 = active ? keys[base + 64 + lane] : 0ull;
-    auto local_stages = [&](int k, int jmax) {       // sub-stages j = jmax .. 1 (jmax <= 64) of merge size k, in registers
-        for (int j = jmax; j > 0; j >>= 1) {
-            if (j == 64) {
-                const bool desc = ((base + lane) & k) == 0;
-                const bool sw = desc ? (e0 < e1) : (e0 > e1);
-                const u64 a = sw ? e1 : e0, b = sw ? e0 : e1;
-                e0 = a; e1 = b;
-            } else {
-                const u64 p0 = shfl_xor_u64(e0, j), p1 = shfl_xor_u64(e1, j);
-                const bool upper = (lane & j) != 0;           // this lane holds the element with the larger index of the pair
-                const bool d0 = ((base + lane) & k) == 0, d1 = ((base + 64 + lane) & k) == 0;
-                // descending block: the lower index keeps the larger key
-                e0 = (d0 != upper) ? (e0 > p0 ? e0 : p0) : (e0 < p0 ? e0 : p0);
-                e1 = (d1 != upper) ? (e1 > p1 ? e1 : p1) : (e1 < p1 ? e1 : p1);
-            }
-        }
+    // compare-exchange of a lane's key with its partner's: the lane keeps the larger one iff keep_max. One 64-bit compare, the
+    // decision is a mask operation on the scalar unit (keys are distinct, or equal zeros where either outcome is the same), two selects.
+    auto cx = [](u64 &e, const u64 p, const bool keep_max) {
+        const bool lt = e < p;
+        e = (lt == keep_max) ? p : e;
     };
-    for (int k = 2; k <= n; k <<= 1) {
-        int j = k >> 1;
-        if (j >= 128) {
+    // Merge sizes and distances are compile-time constants in every copy of the body: the lane masks ((lane & j) != 0, the block
+    // direction for k <= 64) fold into scalar constants, and for k >= 128 the direction is wave-uniform. (The rolled version spent
+    // ~30 VALU instructions per sub-stage on them — 17.5 us for 2048 keys with four waves per SIMD issuing the same code.)
+#pragma unroll
+    for (int lk = 1; lk <= 11; ++lk) {
+        const int k = 1 << lk;
+        if (k > n) break;
+        if (k >= 256) {
             // distances >= 128: through LDS, one barrier pair per sub-stage
             if (active) { keys[base + lane] = e0; keys[base + 64 + lane] = e1; }
             __syncthreads();
-            for (; j >= 128; j >>= 1) {
+            for (int j = k >> 1; j >= 128; j >>= 1) {
                 for (int i = threadIdx.x; i < n; i += blockDim.x) {
                     const int ixj = i ^ j;
                     if (ixj > i) {
@@ -118,9 +112,27 @@ __device__ __forceinline__ void bitonic_sort_desc_hybrid(u64 *keys, int n) {    
             }
             if (active) { e0 = keys[base + lane]; e1 = keys[base + 64 + lane]; }
         }
-        if (active) local_stages(k, j < 64 ? j : 64);
+        if (!active) continue;
+        // the block of merge size k that holds this wave's keys sorts descending iff its index is even
+        const bool d0 = k >= 128 ? ((base & k) == 0) : (k == 64 ? true : ((lane & k) == 0));
+        const bool d1 = k >= 128 ? ((base & k) == 0) : (k == 64 ? false : ((lane & k) == 0));
+#pragma unroll
+        for (int lj = 6; lj >= 0; --lj) {
+            const int j = 1 << lj;
+            if (j > (k >> 1)) continue;
+            if (j == 64) {      // partner inside the lane (k >= 128: d0 == d1)
+                const bool sw = d0 ? (e0 < e1) : (e0 > e1);
+                const u64 a = sw ? e1 : e0, b = sw ? e0 : e1;
+                e0 = a; e1 = b;
+            } else {
+                const u64 p0 = shfl_xor_u64(e0, j), p1 = shfl_xor_u64(e1, j);
+                const bool upper = (lane & j) != 0;           // this lane holds the element with the larger index of the pair
+                cx(e0, p0, d0 != upper);                      // descending block: the lower index keeps the larger key
+                cx(e1, p1, d1 != upper);
+            }
+        }
     }
-    if (active) { keys[base + lane] = e0; keys[base + 64 + lane] = e1; }
+    if (active) { keys[base + lane] = e0; keys[base + 64 + lane] = e1; }      // a wave's own 128 slots: nobody else reads them before the barrier
     __syncthreads();
 }
 
