@@ -96,7 +96,7 @@ __device__ __forceinline__ int lv_word(const Lv &L, int b, int z, int py, int px
 // row of the site (b, z, y, x), or -1. Branch-free: the word, its base and the row are loaded whatever the outcome (word 0 /
 // rank 0 stand in), so that independent lookups of one thread overlap instead of waiting for each other's bit test.
 __device__ __forceinline__ int lv_find(const Lv &L, int b, int z, int y, int x) {
-    const bool in = (unsigned)z < (unsigned)L.Z && (unsigned)y < (unsigned)L.Y && (unsigned)x < (unsigned)L.X;
+    const bool in = (unsigned)z < (unsigned)L.Z && (unsigned)y < (unsigned)L.Y && (unsigned)x < (unsigned)L.X && (unsigned)b < (unsigned)L.B;
     const int w = in ? lv_word(L, b, z, y >> 3, x >> 3) : 0;
     const unsigned long long bits = L.bits[w];
     const int base = L.base[w];
@@ -658,6 +658,9 @@ __device__ __forceinline__ int ix_div_small(int k, int d) {      // k < 256, d i
 // A wave serves 64 >> lg consecutive rows, 1 << lg lanes each (the padded width of the rows' ktotal table entries): consecutive
 // lanes share a site, the table rows are written coalesced, and no index needs a run-time division.
 __global__ __launch_bounds__(IX_BLOCK) void ix_neighbors(Lv Out, NbrJobs J, int lg) {
+    // the row count is only needed by the stores: rows up to the capacity are looked up whatever it says (coordinates beyond the live
+    // rows are stale or zero: lv_find checks every component), so the count's round trip overlaps the coordinate loads instead of
+    // preceding them
     int n = *Out.count;
     if (n > Out.cap) n = Out.cap;
     const int lane = threadIdx.x & 63;
@@ -688,14 +691,15 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_neighbors(Lv Out, NbrJobs J, int 
     const int oz = kz - g.pz, oy = ky - g.py, ox = kx - g.px;
     // four rows per lane and round: their lookups are independent chains (coords -> word + base -> row) that overlap
     constexpr int U = 4;
-    for (int wv = (blockIdx.x * (IX_BLOCK / 64) + (threadIdx.x >> 6)) * U; wv * rpw < n; wv += nwaves * U) {
+    for (int wv = (blockIdx.x * (IX_BLOCK / 64) + (threadIdx.x >> 6)) * U; wv * rpw < Out.cap; wv += nwaves * U) {
         int m[U];
         int4 c[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             m[u] = (wv + u) * rpw + sub;
-            c[u] = reinterpret_cast<const int4 *>(Out.coords)[m[u] < n ? m[u] : 0];
+            c[u] = reinterpret_cast<const int4 *>(Out.coords)[m[u] < Out.cap ? m[u] : 0];
         }
+        if (wv * rpw >= n) break;
         int r[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) r[u] = lv_find(In, c[u].x, c[u].y * g.sz + oz, c[u].z * g.sy + oy, c[u].w * g.sx + ox);
@@ -961,7 +965,7 @@ extern "C" int aq3d_level_neighbors(const aq3d_level *out, const aq3d_nbr_job *j
     AQ3D_REQUIRE(J.ktotal <= 64, "aq3d_level_neighbors: the tables of one launch hold %d > 64 entries per row", J.ktotal);
     int lg = 0;
     while ((1 << lg) < J.ktotal) ++lg;
-    const int rows_per_block = (IX_BLOCK / 64) * (64 >> lg) * 4;
+    const int rows_per_block = (IX_BLOCK / 64) * (64 >> lg) * 4 * 4;     // four rounds of four rows per wave (the job / tap set-up of a wave costs as much as a round; 1 / 4 / 8 rounds: 15.4 / 12.8 / 16.7 us)
     hipLaunchKernelGGL(ix_neighbors, dim3(aq3d_grid(aq3d_div_up(Out.cap, rows_per_block), 1, 16384)), dim3(IX_BLOCK), 0, stream, Out, J, lg);
     AQ3D_CHECK_LAUNCH("aq3d_level_neighbors");
     return AQ3D_OK;
