@@ -238,9 +238,11 @@ __global__ __launch_bounds__(256) void spconv_kernel(SpconvGroup grp) {
 // fp32 activations x int8 weight codes on the fp16 matrix pipe (VoxelNeXt's weight-only QConv2d head: grouped 3x3 / 1x1 sparse
 // 2-D convs). Same tiling, gather and epilogue as spconv_kernel<.., false, true>; the staged operands are fp16 instead of fp32:
 // an activation x goes to LDS as hi = f16(x) and lo' = f16((x - hi) * 2^11) (x == hi + lo exactly; 22 significant bits), a weight
-// code is an exact small integer in fp16, and every 32-deep K chunk costs two v_mfma_f32_16x16x32_f16 (hi, then lo' scaled by
-// 2^-11 in registers — MFMA honours fp16 subnormals — into the SAME fp32 accumulator) instead of eight fp32 MFMAs of twice
-// the latency. Products are exact in fp32; only the 2^-22 tail of each activation is dropped.
+// code is an exact small integer in fp16, and every 32-deep K chunk costs two v_mfma_f32_16x16x32_f16 (hi into one fp32
+// accumulator, lo' into a second one that the epilogue folds in as acc + 2^-11 * acc_lo) instead of eight fp32 MFMAs of twice
+// the latency. Products are exact in fp32; only the 2^-22 tail of each activation is dropped. (Rounds 1-2 scaled lo' by 2^-11 IN
+// fp16 and used one accumulator: for |x| below ~2^-3 that product is an fp16 subnormal and the bits the scaling was meant to keep
+// were lost — ADVICE r2; tests/test_sparse_gpu.py::test_spconv_f32_small_and_large_magnitudes.)
 typedef _Float16 sp_f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 sp_f16x4 __attribute__((ext_vector_type(4)));
 // W32: fp32 weights (an un-quantised layer), split into fp16 hi | lo planes while staged, three MFMAs per product like
@@ -269,8 +271,6 @@ __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
     const int wr = wave % WR, wc = wave / WR;
     const int g = lane >> 4, l15 = lane & 15;
     const int kvol = a.kvol;
-    const _Float16 s11 = (_Float16)(1.0f / 2048.f);
-    const sp_f16x8 lo_scale = {s11, s11, s11, s11, s11, s11, s11, s11};
 
     int n = *a.count_out;
     if (n > a.cap_out) n = a.cap_out;
@@ -284,9 +284,9 @@ __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
             int r = row0 + t / kvol;
             nbr_s[t] = (r < n) ? a.nbr[(size_t)row0 * kvol + t] : -1;
         }
-        f32x4 acc[NT];
+        f32x4 acc[NT], accl[NT];        // products with the hi halves | with one lo' half (scaled by 2^11)
 #pragma unroll
-        for (int i = 0; i < NT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < NT; ++i) { acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; accl[i] = acc[i]; }
         __syncthreads();
 
         for (int k = 0; k < kvol; ++k) {
@@ -350,15 +350,15 @@ __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
 #pragma unroll 2
             for (int kc = 0; kc < CIN; kc += 32) {
                 const sp_f16x8 fh = *reinterpret_cast<const sp_f16x8 *>(ah + kc);
-                const sp_f16x8 fl = *reinterpret_cast<const sp_f16x8 *>(al + kc) * lo_scale;
+                const sp_f16x8 fl = *reinterpret_cast<const sp_f16x8 *>(al + kc);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const sp_f16x8 fb = *reinterpret_cast<const sp_f16x8 *>(bh + nt * 16 * LDH + kc);
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, fb, acc[nt], 0, 0, 0);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, fb, acc[nt], 0, 0, 0);
+                    accl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, fb, accl[nt], 0, 0, 0);
                     if (W32) {
-                        const sp_f16x8 fbl = *reinterpret_cast<const sp_f16x8 *>(bh + COUT * LDH + nt * 16 * LDH + kc) * lo_scale;
-                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, fbl, acc[nt], 0, 0, 0);
+                        const sp_f16x8 fbl = *reinterpret_cast<const sp_f16x8 *>(bh + COUT * LDH + nt * 16 * LDH + kc);
+                        accl[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, fbl, accl[nt], 0, 0, 0);
                     }
                 }
             }
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
             for (int r = 0; r < 4; ++r) {
                 const int m = row0 + wr * 16 + 4 * g + r;
                 if (m < n) {
-                    float v = acc[nt][r];
+                    float v = __fadd_rn(acc[nt][r], __fmul_rn(accl[nt][r], 1.0f / 2048.f));
                     if (a.w_dequant) v = v * wdq;
                     if (a.bias) v = v + b;
                     if (a.post_scale) v = v * ps + pt;

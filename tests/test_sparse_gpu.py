@@ -238,6 +238,38 @@ def test_spconv_f32(dev, cin, cout):
     np.testing.assert_allclose(amax.cpu().numpy(), np.abs(y).max(axis=0), rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("scale", [1e-3, 1.0, 1e4])
+@pytest.mark.parametrize("cout", [128, 16])
+def test_spconv_f32_small_and_large_magnitudes(dev, cout, scale):
+    """The un-quantised 128 -> 128 / 128 -> 16 sparse convs run on the fp16 matrix pipe with both operands split into hi | lo halves;
+    the result has to stay fp32-accurate RELATIVE TO ITS OWN SCALE for activations far from O(1) too (the lo half used to
+    be rescaled in fp16 and fell into subnormals for |x| < 2^-3). Reference: float64. |x| stays below the fp16 range (65504)."""
+    from amdq3d import ops
+    cin = 128
+    idx, shape = _sparse_input(dev, m_pts=2500, seed=cout + 3, batch=1)
+    m = len(idx)
+    rng = np.random.default_rng(cout + int(np.log10(scale)) + 5)
+    feats = np.clip(rng.normal(0, 1, (m, cin)), -5.5, 5.5).astype(np.float32) * np.float32(scale)
+    w = (rng.normal(0, 1, (cout, 3, 3, 3, cin)) / np.sqrt(27 * cin)).astype(np.float32)
+    nbr_ref = OS.subm_neighbors(idx, shape)
+    wk64 = w.reshape(cout, 27, cin).astype(np.float64)
+    ref = np.zeros((m, cout), np.float64)
+    for k in range(27):
+        src = nbr_ref[:, k]
+        hit = src >= 0
+        ref[hit] += feats[src[hit]].astype(np.float64) @ wk64[:, k, :].T
+    cap = m + 11
+    nbr = torch.full((cap, 27), -1, dtype=torch.int32, device=dev)
+    nbr[:m] = torch.from_numpy(nbr_ref).to(dev)
+    count = torch.tensor([m], dtype=torch.int32, device=dev)
+    fin = torch.zeros((cap, cin), device=dev); fin[:m] = torch.from_numpy(feats).to(dev)
+    wk = torch.from_numpy(np.ascontiguousarray(w.reshape(cout, 27, cin).transpose(1, 0, 2))).to(dev)
+    y = ops.spconv(fin, wk, nbr, count, cout)[:m].cpu().numpy().astype(np.float64)
+    assert np.isfinite(y).all()
+    err = np.abs(y - ref).max() / np.abs(ref).max()
+    assert err <= 2e-6, err
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (128, 128)])
 def test_spconv_int8_codes(dev, cin, cout):
     """QConvNd semantics: per-column activation codes (scale folded into the gather) x per-out-channel weight codes."""
