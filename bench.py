@@ -497,7 +497,7 @@ def main():
                 with open(os.path.join(ROOT, cand)) as f:
                     tj = json.load(f)
                 traffic = {k: v for k, v in tj.items() if not k.startswith("_")}
-                traffic_meta = dict({k: v for k, v in tj.items() if k.startswith("_")}, file=cand)
+                traffic_meta = dict({k: v for k, v in tj.items() if k in ("_commit", "_note")}, file=cand)
                 break
             except Exception:
                 continue
