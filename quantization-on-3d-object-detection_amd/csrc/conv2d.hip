@@ -644,6 +644,8 @@ extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n,
     // 2K floats of dynamic LDS cost more occupancy than the loads: Cin = 256: 50 -> 73 us, Cin = 512: 71 -> 101 us, Cin = 128 unchanged)
     // (measured round 2, W150k: forcing 32-pixel tiles or 8 waves per workgroup on the 188 x 188 layers — more waves per SIMD — is
     // 25-30 % SLOWER, and so is a two-step-deep load prefetch: per-workgroup fixed work and weight staging, not load latency, bound it)
+    // (measured round 3: 48-pixel tiles on 6 waves, <4, 1, 3>: 737 workgroups = 2.9 per CU instead of 553 = 2.2 with some CUs at 3 — or
+    // 80-pixel tiles on 10 waves — 28.4 -> 33.5 / 34.7 us for 128 -> 128 at 188 x 188: four MFMAs per wave and step do not cover the step's chain)
     // pixel tiles are dealt to the 8 XCDs in contiguous ranges (grid x padded to a multiple of 8): vertically adjacent tiles of a
     // 3x3 conv re-read each other's input rows and then share an L2
     for (int i = 0; i < AQ3D_MAX_GROUP; ++i) grp.p[i].xcd_order = 1;
