@@ -332,6 +332,7 @@ typedef struct aq3d_conv2d_problem {
     float *y;
     float *pieces_out;
     int32_t pieces_ld, pieces_mode;
+    const void *weight_split;          /* f32, optional: aq3d_conv2d_split_weight of the same weights (used by 1x1 / deconv GEMMs) */
 } aq3d_conv2d_problem;
 
 /* Up to 8 independent convolutions of one launch class (same H, W, Cin, ksize, stride, pad; Cout on the same side of 128
@@ -339,6 +340,10 @@ typedef struct aq3d_conv2d_problem {
  * (pcdet/models/dense_heads/center_head.py:12-46), each too small to fill the chip on its own. */
 int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *problems, int32_t n, void *stream);
 int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *problems, int32_t n, void *stream);
+
+/* weight f32 [rows, K] → out f16 [rows, 2, K]: hi = f16(w) | lo' = f16((w - hi) * 2^11), the operand form the fp32 convs use on the
+ * fp16 matrix pipe (weight_split above). Done once per weight: every pixel tile of a launch otherwise repeats the split. */
+int aq3d_conv2d_split_weight(const float *weight, int64_t rows, int32_t K, void *out, void *stream);
 
 /* fp32 conv / transposed conv (MFMA f32), weight f32 [Cout_total, K] with K ordered (kh, kw, c);
  * for deconv = d the weight rows are ordered (i, j, o): row = (i*d + j)*Cout + o. */

@@ -25,6 +25,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct ConvArgs {
     const float *x;
     const void *w;          // i8 path: int8 [Cout][K];  f32 path: f32 [Cout_total][K]
+    const void *w16;        // f32 path, optional: the same weights split into fp16 planes [Cout_total][2][K] (aq3d_conv2d_split_weight)
     const float *s;         // i8: smoothing scale per column [K]
     const float *rinv;      // i8: 1/s
     const float *scal;      // i8: scal[0] = activation quant scale
@@ -670,6 +671,7 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
                               int32_t pieces_ld, int32_t pieces_mode, void *stream_) {
     AQ3D_REQUIRE(g, "aq3d_conv2d_i8: null argument");
     aq3d_conv2d_problem q;
+    q.weight_split = nullptr;
     q.x = x; q.weight_or_params = params; q.geom = g; q.bias = bias; q.post_scale = post_scale; q.post_shift = post_shift;
     q.y = y; q.pieces_out = pieces_out; q.pieces_ld = pieces_ld; q.pieces_mode = pieces_mode;
     return aq3d_conv2d_i8_group(&q, 1, stream_);
@@ -691,7 +693,12 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 // exactly what the reference multiplies: x' = clamp(rint((x / s) * sx)) / sx per (pixel, tap, channel) while the tile is
 // staged (exact quotients by Markstein correction), weights = the int8 codes of aq3d_sq_prep as fp32 (exact in the hi half),
 // per-channel weight step applied in the epilogue (a.out_mul).
-template <int WM, int WN, int TI, int TJ, int KS, bool SQ = false>
+// K1 = true: a plain GEMM over the pixels (1x1 conv, or kernel == stride transposed conv) with the weights already split into fp16
+// planes by aq3d_conv2d_split_weight: the per-item offsets and bounds are computed once (a step only adds the channel offset as the
+// buffer load's scalar offset), the weight halves go from global memory to LDS as they are. The three deblocks of the BEV backbone:
+// of ~280 instructions per K step of the general loop ~100 were address / bounds / branch work and ~50 the weight split that every one
+// of the 550-1100 pixel tiles repeated.
+template <int WM, int WN, int TI, int TJ, int KS, bool SQ = false, bool K1 = false>
 __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
     const ConvArgs a = grp.p[blockIdx.z];
     // Tile order: the row (output-channel) blocks of ONE pixel tile re-read the same input pixels, so they are dispatched back to
@@ -803,6 +810,51 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
         }
     };
 
+    // ---- K1: GEMM staging
+    constexpr int WQ = KS / 8;                          // 16-byte groups of 8 halves per row, plane and step
+    constexpr int WI16 = (BM * WQ + 255) / 256;
+    unsigned xoff[XI], woff[WI16];
+    i32x4 wh[WI16], wl[WI16];
+    const auto rsrc_x1 = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, K1 ? a.H * a.W * a.in_ld * 4 : 0, 0x00020000);
+    const auto rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc((void *)a.w16, 0, K1 ? a.rows_total * K * 4 : 0, 0x00020000);
+    if (K1) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int item = tid + 256 * i, pix = item / QPR, p = pix0 + pix;
+            xoff[i] = (pix < BN && p < L) ? (unsigned)(p * a.in_ld + (item % QPR) * 4) * 4u : 0xfffffff0u;
+        }
+#pragma unroll
+        for (int i = 0; i < WI16; ++i) {
+            const int item = tid + 256 * i, row = item / WQ;
+            woff[i] = (row < BM && row0 + row < a.rows_total) ? (unsigned)((row0 + row) * 2 * K + (item % WQ) * 8) * 2u : 0xfffffff0u;
+        }
+    }
+    auto load_step1 = [&](int kstep) {       // out-of-range items: the vector offset alone is range-checked, they read zeros
+        const int c0 = kstep * KS;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x1, xoff[i], c0 * 4, 0));
+#pragma unroll
+        for (int i = 0; i < WI16; ++i) {
+            wh[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w1, woff[i], c0 * 2, 0));
+            wl[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w1, woff[i], (K + c0) * 2, 0));
+        }
+    };
+    auto store_step1 = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int item = tid + 256 * i;
+            if (item / QPR < BN) put_split(Xbuf(buf) + (item / QPR) * LD, item % QPR, xr[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < WI16; ++i) {
+            const int item = tid + 256 * i, row = item / WQ;
+            if (BM * WQ % 256 == 0 || row < BM) {
+                *reinterpret_cast<i32x4 *>(Wbuf(buf) + row * LD + (item % WQ) * 8) = wh[i];
+                *reinterpret_cast<i32x4 *>(Wbuf(buf) + row * LD + KS + (item % WQ) * 8) = wl[i];
+            }
+        }
+    };
+
     f32x4 acc[TI][TJ], accl[TI][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i)
@@ -859,15 +911,28 @@ __global__ __launch_bounds__(256) void conv2d_f16s_kernel(ConvGroup grp) {
             }
         }
     }
-    load_step(0);
-    store_step(0);
-    __syncthreads();
-    for (int k = 0; k + 1 < nk; ++k) {       // branch-free steady state, last step peeled (see conv2d_i8_kernel)
-        const int buf = k & 1;
-        load_step(k + 1);
-        mma_step(buf);
-        store_step(buf ^ 1);
+    if (K1) {
+        load_step1(0);
+        store_step1(0);
         __syncthreads();
+        for (int k = 0; k + 1 < nk; ++k) {
+            const int buf = k & 1;
+            load_step1(k + 1);
+            mma_step(buf);
+            store_step1(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        load_step(0);
+        store_step(0);
+        __syncthreads();
+        for (int k = 0; k + 1 < nk; ++k) {       // branch-free steady state, last step peeled (see conv2d_i8_kernel)
+            const int buf = k & 1;
+            load_step(k + 1);
+            mma_step(buf);
+            store_step(buf ^ 1);
+            __syncthreads();
+        }
     }
     mma_step((nk - 1) & 1);
 
@@ -1009,6 +1074,7 @@ static int prep_f32(ConvArgs *a, const aq3d_conv2d_problem *q, int *L_out) {
     AQ3D_REQUIRE(q->weight_or_params, "aq3d_conv2d_f32: null weight");
     AQ3D_REQUIRE((g->Cin & 15) == 0, "aq3d_conv2d_f32: Cin=%d must be a multiple of 16", g->Cin);
     a->w = q->weight_or_params;
+    a->w16 = q->weight_split;
     if (g->deconv > 0) {
         AQ3D_REQUIRE(g->ksize == 1 && g->stride == 1 && g->pad == 0, "aq3d_conv2d_f32: deconv needs ksize=1 stride=1 pad=0 (kernel == stride == deconv)");
         AQ3D_REQUIRE(g->Ho == g->H && g->Wo == g->W, "aq3d_conv2d_f32: deconv takes Ho=H, Wo=W (the input grid)");
@@ -1023,6 +1089,25 @@ static int prep_f32(ConvArgs *a, const aq3d_conv2d_problem *q, int *L_out) {
 }
 
 static int f32_class(int rows, int L) { return rows <= 16 ? 0 : ((rows <= 64 || L < 128 * 150) ? 1 : 2); }
+
+// fp32 weights [rows][K] -> fp16 planes [rows][2][K]: hi = f16(w), lo' = f16((w - hi) * 2^11) — the operand form of conv2d_f16s_kernel
+__global__ __launch_bounds__(256) void split_weight_kernel(const float *__restrict__ w, long long n, int K, _Float16 *__restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const long long r = i / K;
+        const int k = (int)(i - r * K);
+        const float v = w[i];
+        const _Float16 h = (_Float16)v;
+        out[(r * 2) * K + k] = h;
+        out[(r * 2 + 1) * K + k] = (_Float16)__fmul_rn(__fsub_rn(v, (float)h), 2048.f);
+    }
+}
+extern "C" int aq3d_conv2d_split_weight(const float *weight, int64_t rows, int32_t K, void *out, void *stream_) {
+    AQ3D_REQUIRE(weight && out && rows >= 1 && K >= 1, "aq3d_conv2d_split_weight: bad argument");
+    hipLaunchKernelGGL(split_weight_kernel, dim3(aq3d_grid(rows * K, 256)), dim3(256), 0, (hipStream_t)stream_, weight, (long long)rows * K, K,
+                       static_cast<_Float16 *>(out));
+    AQ3D_CHECK_LAUNCH("aq3d_conv2d_split_weight");
+    return AQ3D_OK;
+}
 
 extern "C" int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *probs, int32_t n, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1050,7 +1135,13 @@ extern "C" int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *probs, int32_t n
         } else {        // 64 x 64 tiles for both deblock shapes (128-row tiles measured slower: conversion work, 63 KB of LDS; 64-deep K steps: no gain)
             const int nrb = aq3d_div_up(max_rows, 64);
             for (int i = 0; i < AQ3D_MAX_GROUP; ++i) grp.p[i].nrb = nrb;
-            hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 32>), dim3(aq3d_div_up(aq3d_div_up(L, 64), 8) * 8 * nrb, 1, n), dim3(256), 0, stream, grp);
+            bool k1 = true;         // plain GEMMs with pre-split weights (the deblocks)
+            for (int i = 0; i < n; ++i)
+                k1 = k1 && probs[i].weight_split && probs[i].geom->ksize == 1 && probs[i].geom->stride == 1 && probs[i].geom->pad == 0 &&
+                     (long long)grp.p[i].rows_total * probs[i].geom->Cin * 4 < 0x7fffffffLL &&
+                     (long long)probs[i].geom->H * probs[i].geom->W * probs[i].geom->in_ld * 4 < 0x7fffffffLL;
+            if (k1) hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 32, false, true>), dim3(aq3d_div_up(aq3d_div_up(L, 64), 8) * 8 * nrb, 1, n), dim3(256), 0, stream, grp);
+            else hipLaunchKernelGGL((conv2d_f16s_kernel<2, 2, 2, 2, 32>), dim3(aq3d_div_up(aq3d_div_up(L, 64), 8) * 8 * nrb, 1, n), dim3(256), 0, stream, grp);
         }
         AQ3D_CHECK_LAUNCH("aq3d_conv2d_f32");
         return AQ3D_OK;
@@ -1101,6 +1192,7 @@ extern "C" int aq3d_conv2d_sq16(const float *x, const void *params, const aq3d_c
     hipLaunchKernelGGL(sq16_expand_kernel, dim3(aq3d_grid((int64_t)g->Cout * K, 256, 1024)), dim3(256), 0, stream, (const int8_t *)(base + l.wq),
                        (const float *)(base + l.amaxw), g->Cout, K, (float)((1 << (w_bits - 1)) - 1), wf, wstep);
     aq3d_conv2d_problem q;
+    q.weight_split = nullptr;
     q.x = x; q.weight_or_params = wf; q.geom = g; q.bias = bias; q.post_scale = post_scale; q.post_shift = post_shift;
     q.y = y; q.pieces_out = nullptr; q.pieces_ld = 0; q.pieces_mode = 0;
     ConvGroup grp;
@@ -1121,6 +1213,7 @@ extern "C" int aq3d_conv2d_f32(const float *x, const float *weight, const aq3d_c
                                int32_t pieces_ld, void *stream_) {
     AQ3D_REQUIRE(g, "aq3d_conv2d_f32: null argument");
     aq3d_conv2d_problem q;
+    q.weight_split = nullptr;
     q.x = x; q.weight_or_params = weight; q.geom = g; q.bias = bias; q.post_scale = post_scale; q.post_shift = post_shift;
     q.y = y; q.pieces_out = pieces_out; q.pieces_ld = pieces_ld; q.pieces_mode = 0;
     return aq3d_conv2d_f32_group(&q, 1, stream_);

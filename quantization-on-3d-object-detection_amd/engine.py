@@ -486,6 +486,8 @@ class Engine:
                 g = ops.conv_geom(xH, xW, cin, cout, 1, 1, 0, in_ld=x_ld, out_ld=out_ld or cout, out_coff=out_coff,
                                   deconv=d, relu=relu)
                 rec["weight"] = ops.deconv_weight_to_k(mod.weight.detach().float()).to(dev)
+                if cin % 32 == 0:       # the deblock GEMMs take their weights pre-split into fp16 planes (constant per model)
+                    rec["w_split"] = ops.split_weight(rec["weight"])
                 Ho, Wo = xH * d, xW * d
                 rec["kind"] = "f32"
             else:
@@ -1042,7 +1044,7 @@ class Engine:
             with _Timed(self, "conv2d_f32"):
                 for b in range(B):
                     ops.conv2d_f32(x[b], rec["weight"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b],
-                                   pieces_out=po)
+                                   pieces_out=po, weight_split=rec.get("w_split"))
 
     def _harvest_calib(self, rec, cal, B):
         """Calibration forward of an SQConv2d/QuantConv2d: the amax its two quantizers would see this batch."""

@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 
 class Aq3dError(RuntimeError):
@@ -48,7 +48,7 @@ class HeadProblem(Structure):
 class Conv2dProblem(Structure):
     _fields_ = [("x", c_void_p), ("weight_or_params", c_void_p), ("geom", POINTER(Conv2dGeom)), ("bias", c_void_p),
                 ("post_scale", c_void_p), ("post_shift", c_void_p), ("y", c_void_p), ("pieces_out", c_void_p),
-                ("pieces_ld", c_int32), ("pieces_mode", c_int32)]
+                ("pieces_ld", c_int32), ("pieces_mode", c_int32), ("weight_split", c_void_p)]
 
 
 class SpconvProblem(Structure):
@@ -109,6 +109,7 @@ SIGNATURES = {
     "aq3d_sq_prep_group": (c_int32, [POINTER(SqPrepProblem), c_int32, c_int32, c_int32, P]),
     "aq3d_conv2d_i8_group": (c_int32, [POINTER(Conv2dProblem), c_int32, P]),
     "aq3d_conv2d_f32_group": (c_int32, [POINTER(Conv2dProblem), c_int32, P]),
+    "aq3d_conv2d_split_weight": (c_int32, [P, ctypes.c_int64, c_int32, P, P]),
     "aq3d_conv2d_i8": (c_int32, [P, P, POINTER(Conv2dGeom), P, P, P, P, P, c_int32, c_int32, P]),
     "aq3d_conv2d_f32": (c_int32, [P, P, POINTER(Conv2dGeom), P, P, P, P, P, c_int32, P]),
     "aq3d_conv2d_sq16_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),

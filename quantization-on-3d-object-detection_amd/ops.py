@@ -435,6 +435,7 @@ def conv_problems(recs):
         q.bias, q.post_scale, q.post_shift = _addr(r.get("bias")), _addr(r.get("post_scale")), _addr(r.get("post_shift"))
         q.y, q.pieces_out = _addr(r["y"]), _addr(po)
         q.pieces_ld, q.pieces_mode = (0 if po is None else int(po.shape[1])), int(r.get("pieces_mode", 0))
+        q.weight_split = _addr(r.get("w_split"))
     return arr
 
 
@@ -462,10 +463,22 @@ def sq_prep_group(problems, w_bits=8, a_bits=8):
     check(_lib.load().aq3d_sq_prep_group(problems, len(problems), int(w_bits), int(a_bits), _stream()), "aq3d_sq_prep_group")
 
 
-def conv2d_f32(x, weight_k, g, bias=None, post_scale=None, post_shift=None, out=None, pieces_out=None):
+def split_weight(weight_k):
+    """f32 [rows, K] → f16 [rows, 2, K] (hi | lo' planes): the pre-split operand of the fp32 GEMMs (conv2d_f32(..., weight_split=))."""
+    rows, K = weight_k.shape
+    out = torch.empty((rows, 2, K), dtype=torch.float16, device=weight_k.device)
+    check(_lib.load().aq3d_conv2d_split_weight(_p(weight_k), rows, K, _p(out), _stream()), "aq3d_conv2d_split_weight")
+    return out
+
+
+def conv2d_f32(x, weight_k, g, bias=None, post_scale=None, post_shift=None, out=None, pieces_out=None, weight_split=None, pieces_mode=0):
     L = _lib.load()
     Ho, Wo = out_hw(g)
     y = out if out is not None else torch.empty((Ho, Wo, g.out_ld), dtype=f32, device=x.device)
+    if weight_split is not None:
+        conv2d_f32_group(conv_problems([dict(x=x, w=weight_k, g=g, bias=bias, post_scale=post_scale, post_shift=post_shift, y=y,
+                                             pieces_out=pieces_out, pieces_mode=pieces_mode, w_split=weight_split)]))
+        return y
     check(L.aq3d_conv2d_f32(_p(x), _p(weight_k), ctypes.byref(g), _p(bias), _p(post_scale), _p(post_shift), _p(y),
                             _p(pieces_out), 0 if pieces_out is None else pieces_out.shape[1], _stream()), "aq3d_conv2d_f32")
     return y

@@ -130,6 +130,14 @@ def test_deconv_f32(dev, Cin, Cout, H, W, d):
         np.testing.assert_array_equal(po.cpu().numpy(), ops.piece_absmax(buf, H * d, W * d, 2 * Cout).cpu().numpy())
     y = buf.cpu()[..., Cout:].permute(2, 0, 1)[None]
     assert float((y - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    if Cin % 32 == 0:
+        # the same GEMM with the weights split into fp16 planes beforehand (what the engine hands the deblocks): the same products
+        # in the same order — identical output and piece maxima
+        wk = ops.deconv_weight_to_k(w).to(dev)
+        buf2, po2 = torch.zeros_like(buf), torch.zeros_like(po)
+        ops.conv2d_f32(_nhwc(x).to(dev), wk, geom, None, ps.to(dev), pt.to(dev), out=buf2, pieces_out=po2, weight_split=ops.split_weight(wk))
+        np.testing.assert_array_equal(buf2.cpu().numpy(), buf.cpu().numpy())
+        np.testing.assert_array_equal(po2.cpu().numpy(), po.cpu().numpy())
 
 
 def _head_maps(H, W, ncls, seed, peaks=300):
