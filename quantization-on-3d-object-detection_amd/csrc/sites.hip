@@ -480,7 +480,9 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_rank(Lv L, IxWs ws) {
     if (w >= L.words) return;
     L.base[w] = r;
     const int per_sample = L.words / L.B;
-    if (w % per_sample == 0) ws.sstart[w / per_sample] = r;
+    for (int b = 0; b < L.B; ++b)           // (no per-thread division: nearly every word of a level is empty and its thread ends here)
+        if (w == b * per_sample) ws.sstart[b] = r;
+    if (!v) return;
     if (L.sorted) {
         while (v) {
             const int bit = __builtin_ctzll(v);
