@@ -1044,7 +1044,8 @@ class Engine:
             with _Timed(self, "conv2d_f32"):
                 for b in range(B):
                     ops.conv2d_f32(x[b], rec["weight"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b],
-                                   pieces_out=po, weight_split=rec.get("w_split"))
+                                   pieces_out=po, weight_split=rec.get("w_split"),
+                                   pieces_mode=rec["pieces_out"][2] if po is not None else 0)
 
     def _harvest_calib(self, rec, cal, B):
         """Calibration forward of an SQConv2d/QuantConv2d: the amax its two quantizers would see this batch."""

@@ -475,7 +475,7 @@ def conv2d_f32(x, weight_k, g, bias=None, post_scale=None, post_shift=None, out=
     L = _lib.load()
     Ho, Wo = out_hw(g)
     y = out if out is not None else torch.empty((Ho, Wo, g.out_ld), dtype=f32, device=x.device)
-    if weight_split is not None:
+    if weight_split is not None or pieces_mode:
         conv2d_f32_group(conv_problems([dict(x=x, w=weight_k, g=g, bias=bias, post_scale=post_scale, post_shift=post_shift, y=y,
                                              pieces_out=pieces_out, pieces_mode=pieces_mode, w_split=weight_split)]))
         return y
