@@ -166,7 +166,7 @@ def kernel_work(eng, cat):
                 byts += g.H * g.W * g.Cin * 4
                 n += 1
         return byts, 0, n, None
-    if cat == "rulebook":
+    if cat == "index_levels":
         byts = 0
         for lv in eng.levels:
             m = int(lv["count"].item())
@@ -186,7 +186,7 @@ def family_roofline(eng, cat, ms_per_frame, traffic):
     gbs = byts / n / avg_s / 1e9
     rec = {"kernel": cat, "launches_per_frame": n, "avg_launch_us": avg_s * 1e6, "ms_per_frame": ms_per_frame,
            "algorithmic_bytes_per_launch": byts / n,
-           "traffic": traffic.get(cat, traffic.get("index") if cat in ("voxelize", "rulebook") else None)}
+           "traffic": traffic.get(cat, traffic.get("index") if cat in ("voxelize", "index_levels") else None)}
     if b16 is not None:
         rec["algorithmic_bytes_per_launch_fp16_activations"] = b16 / n          # SURVEY §8d's convention
         rec["frac_hbm_fp16_activations"] = b16 / n / avg_s / 1e9 / HBM_PEAK_GBS

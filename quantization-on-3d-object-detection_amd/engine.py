@@ -1,7 +1,7 @@
 """Device plan of the CenterPoint hot path: compiles the parameter containers (modules.py) and quantisation
 descriptors (quant.py) into preallocated device buffers + an ordered list of HIP kernel launches, then runs a frame.
 
-One forward = voxelize → rulebook (5 index levels) → 21 sparse convs → sparse→dense → 12 BEV convs + 2 deblocks →
+One forward = voxelize → index levels (5 bitmap levels + gather tables) → 21 sparse convs → sparse→dense → 12 BEV convs + 2 deblocks →
 shared conv + head branches → decode → rotated NMS, all enqueued on the current stream with NO device→host
 synchronisation until the final read of the per-sample detection counts. Dynamic sizes stay on the device.
 
@@ -1255,7 +1255,7 @@ class Engine:
                 with _Timed(self, "decode_nms"):
                     self._decode_nms(B)
             elif kind == "bev_merge":
-                with _Timed(self, "rulebook"):
+                with _Timed(self, "index_levels"):
                     self._bev_merge()
             elif kind == "voxel_decode_nms":
                 with _Timed(self, "decode_nms"):
@@ -1264,7 +1264,7 @@ class Engine:
     def _run_index(self, kind, arg):
         # "index_subm" / "index_head" only register tables at compile time: every table of a level is built with the level
         if kind == "index_down":
-            with _Timed(self, "rulebook"):
+            with _Timed(self, "index_levels"):
                 lv_out = self.levels[arg]
                 d = lv_out["down"]
                 ops.level_downsample(self.levels[d["src"]]["index"], d["ksize"], d["stride"], d["pad"], lv_out["index"],

@@ -6,7 +6,7 @@ import collections, csv, glob, json, sys
 FAMILY = [("conv2d_i8_kernel", "conv2d_i8"), ("conv2d_f16s_kernel", "conv2d_f32"), ("conv2d_f32_kernel", "conv2d_f32"),
           ("sp_prep_kernel", "quantize_rows"), ("quantize_rows_kernel", "quantize_rows"), ("piece_absmax_kernel", "piece_absmax"),
           ("sq_prep", "sq_prep"), ("sq_scales", "sq_prep"), ("sq_weights", "sq_prep"), ("scatter_dense_kernel", "scatter_dense"),
-          ("vox_", "voxelize"), ("ix_", "index")]     # ix_*: level-0 build (bench category "voxelize") + strided levels ("rulebook")
+          ("vox_", "voxelize"), ("ix_", "index")]     # ix_*: level-0 build (bench category "voxelize") + strided levels ("index_levels")
 
 
 def family(name):

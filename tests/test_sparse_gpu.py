@@ -1,4 +1,4 @@
-"""GPU parity: voxelizer, rulebook and sparse conv (through the C ABI) vs the CPU oracle.
+"""GPU parity: voxelizer, index levels and sparse conv (through the C ABI) vs the CPU oracle.
 
 Bars: voxel coordinates / counts / gather tables bit-exact; voxel mean features bit-exact (same fp32 op order);
 sparse conv within 2e-5 relative to the row scale (fp32, summation order differs).
