@@ -525,7 +525,9 @@ def center_decode(hm, center, center_z, dim, rot, vel, cfg, workspace=None, out=
     else:
         boxes, scores, labels, count = out
     need = L.aq3d_center_decode_workspace_bytes(ctypes.byref(cfg))
-    if workspace is None or workspace.numel() < need:
+    if isinstance(workspace, str) and workspace == "min":      # the smallest workspace the call accepts: one workgroup per class
+        workspace = torch.empty((cfg.num_classes * cfg.K * 8 + 256,), dtype=torch.uint8, device=dev)
+    elif workspace is None or workspace.numel() < need:
         workspace = torch.empty((need,), dtype=torch.uint8, device=dev)
     check(L.aq3d_center_decode(_pv(hm), _pv(center), _pv(center_z), _pv(dim), _pv(rot), _pv(vel), ctypes.byref(cfg), _p(boxes),
                                _p(scores), _p(labels), _p(count), _p(workspace), workspace.numel(), _stream()),

@@ -179,7 +179,8 @@ def test_center_decode(dev, H, W, ncls, K):
 
 @pytest.mark.parametrize("kind,H,W,ncls,K", [("hover", 188, 188, 3, 500), ("constant", 188, 188, 3, 500), ("constant", 100, 100, 2, 500),
                                               ("steps", 100, 100, 3, 100), ("steps10", 100, 100, 2, 100), ("hover", 180, 180, 2, 83)])
-def test_center_decode_crowded_and_tied_maps(dev, kind, H, W, ncls, K):
+@pytest.mark.parametrize("ws", ["full", "min"])
+def test_center_decode_crowded_and_tied_maps(dev, kind, H, W, ncls, K, ws):
     """The top-K beyond the few-peaks case: more scores above the threshold than the candidate cache holds (the select then runs
     over every pixel's key), and maps full of equal scores (the K winners are the smallest pixel indices, across the chunks the
     score pass is split into) — random-weight heads produce the first, a saturated head the second."""
@@ -205,7 +206,9 @@ def test_center_decode_crowded_and_tied_maps(dev, kind, H, W, ncls, K):
     buf[:, 12:14] = rot.reshape(2, -1).T
     t = torch.from_numpy(buf).to(dev)
     cfg = ops.make_decode_cfg(H, W, ncls, K, False, 8, [0.1, 0.1], pc_range, pc_range, 0.1, 24, 24)
-    boxes, scores, labels, count = ops.center_decode(t, t[:, 4:], t[:, 6:], t[:, 8:], t[:, 12:], None, cfg)
+    # "min": the smallest workspace the call accepts — the one-workgroup-per-class top-K (what maps beyond 36 096 pixels get)
+    boxes, scores, labels, count = ops.center_decode(t, t[:, 4:], t[:, 6:], t[:, 8:], t[:, 12:], None, cfg,
+                                                     workspace="min" if ws == "min" else None)
     n = int(count.item())
     assert n == len(s_ref) and n > 0
     np.testing.assert_array_equal(labels[:n].cpu().numpy(), l_ref)
