@@ -1090,6 +1090,93 @@ static int prep_f32(ConvArgs *a, const aq3d_conv2d_problem *q, int *L_out) {
 
 static int f32_class(int rows, int L) { return rows <= 16 ? 0 : ((rows <= 64 || L < 128 * 150) ? 1 : 2); }
 
+// ------------------------------------------------------------------ fp32 3x3 conv with 1-4 output channels: plain VALU
+// The last conv of every CenterHead branch (64 -> 1..3 channels, left in fp32 by the recipe: quant_centerpoint.py:28-71) has so few
+// output channels that a GEMM tile is almost all padding: on the matrix pipe (16-row tiles, every fp32 input split into fp16 halves
+// once per tap) the five branches of the Waymo head cost 72 us — all of it staging. Here a thread owns one output pixel and keeps its
+// <= 4 sums in registers; the input goes through LDS once per 16-channel chunk as an 18 x 18 halo tile (each element fetched once per
+// tile, not once per tap), the weights of a (tap, channel) are wave-uniform scalar operands of the fp32 FMAs. Sum order: channel chunk,
+// tap, channel — a fixed fp32 FMA chain (the oracle's conv sums in another order: same 2e-5 bar as every fp32 layer).
+template <int CO>
+__device__ __forceinline__ void conv2d_f32_small_body(const ConvArgs &a, float *tile) {
+    constexpr int TS = 16, HS = TS + 2, CC = 16, PS = CC + 4;       // 16 x 16 outputs, 18 x 18 halo, 16-channel chunks, 80-byte pixel rows
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tiles_x = (a.Wo + TS - 1) / TS;
+    const int by = (int)blockIdx.x / tiles_x, bx = (int)blockIdx.x - by * tiles_x;
+    const int oy = by * TS + ty, ox = bx * TS + tx;
+    const int K = a.Cin * 9;
+    const float *w = static_cast<const float *>(a.w);
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+    constexpr int NL = (HS * HS * (CC / 4) + 255) / 256;             // float4 loads per thread and chunk
+    f32x4 v[NL];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int item = tid + 256 * i, px = item >> 2, q = item & 3;
+            const int hy = px / HS, hx = px - hy * HS;
+            const int iy = by * TS + hy - 1, ix = bx * TS + hx - 1;
+            v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (px < HS * HS && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v[i] = *reinterpret_cast<const f32x4 *>(a.x + ((size_t)iy * a.W + ix) * a.in_ld + c0 + q * 4);
+        }
+    };
+    auto store_chunk = [&](float *buf) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int item = tid + 256 * i, px = item >> 2, q = item & 3;
+            if (px < HS * HS) *reinterpret_cast<f32x4 *>(buf + px * PS + q * 4) = v[i];
+        }
+    };
+    const int nchunks = a.Cin / CC;
+    load_chunk(0);
+    store_chunk(tile);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        float *cur = tile + (c & 1) * (HS * HS * PS);
+        if (c + 1 < nchunks) load_chunk((c + 1) * CC);
+        // one tap at a time (rolled): its CO x 16 weights are scalar operands — unrolled over the taps the compiler hoists all 9 x CO x 16
+        // scalar loads of a chunk and spills SGPRs through v_writelane
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const float *pxl = cur + ((ty + dy) * HS + tx + dx) * PS;
+            f32x4 x4[CC / 4];
+#pragma unroll
+            for (int q = 0; q < CC / 4; ++q) x4[q] = *reinterpret_cast<const f32x4 *>(pxl + q * 4);
+            const float *wt = w + (size_t)tap * a.Cin + c * CC;           // wave-uniform
+#pragma unroll
+            for (int o = 0; o < CO; ++o)
+#pragma unroll
+                for (int j = 0; j < CC; ++j) acc[o] = __fmaf_rn(x4[j >> 2][j & 3], wt[(size_t)o * K + j], acc[o]);
+        }
+        if (c + 1 < nchunks) store_chunk(tile + ((c + 1) & 1) * (HS * HS * PS));
+        __syncthreads();
+    }
+    if (oy < a.Ho && ox < a.Wo) {
+        float *dst = a.y + ((size_t)oy * a.Wo + ox) * a.out_ld + a.out_coff;
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            float t = acc[o];
+            if (a.bias) t = __fadd_rn(t, a.bias[o]);
+            if (a.post_scale) t = __fadd_rn(__fmul_rn(t, a.post_scale[o]), a.post_shift[o]);
+            if (a.relu) t = fmaxf(t, 0.f);
+            dst[o] = t;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void conv2d_f32_small_kernel(ConvGroup grp) {
+    const ConvArgs a = grp.p[blockIdx.z];
+    __shared__ __attribute__((aligned(16))) float tile[2 * 18 * 18 * 20];
+    switch (a.Cout) {       // uniform per workgroup; the body is unrolled over the output channels
+    case 1: conv2d_f32_small_body<1>(a, tile); break;
+    case 2: conv2d_f32_small_body<2>(a, tile); break;
+    case 3: conv2d_f32_small_body<3>(a, tile); break;
+    default: conv2d_f32_small_body<4>(a, tile); break;
+    }
+}
+
 // fp32 weights [rows][K] -> fp16 planes [rows][2][K]: hi = f16(w), lo' = f16((w - hi) * 2^11) — the operand form of conv2d_f16s_kernel
 __global__ __launch_bounds__(256) void split_weight_kernel(const float *__restrict__ w, long long n, int K, _Float16 *__restrict__ out) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
@@ -1128,6 +1215,18 @@ extern "C" int aq3d_conv2d_f32_group(const aq3d_conv2d_problem *probs, int32_t n
     for (int i = n; i < AQ3D_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     bool split_ok = true;
     for (int i = 0; i < n; ++i) split_ok = split_ok && (probs[i].geom->Cin & 31) == 0;
+    bool small_ok = cls == 0;       // 3x3, stride 1, pad 1, <= 4 output channels, no piece maxima: the VALU kernel
+    for (int i = 0; i < n; ++i) {
+        const aq3d_conv2d_geom *g_ = probs[i].geom;
+        small_ok = small_ok && g_->ksize == 3 && g_->stride == 1 && g_->pad == 1 && g_->deconv == 0 && g_->Cout >= 1 && g_->Cout <= 4 &&
+                   (g_->Cin & 15) == 0 && !probs[i].pieces_out;
+    }
+    if (small_ok) {
+        const aq3d_conv2d_geom *g_ = probs[0].geom;
+        hipLaunchKernelGGL(conv2d_f32_small_kernel, dim3(aq3d_div_up(g_->Ho, 16) * aq3d_div_up(g_->Wo, 16), 1, n), dim3(256), 0, stream, grp);
+        AQ3D_CHECK_LAUNCH("aq3d_conv2d_f32");
+        return AQ3D_OK;
+    }
     if (split_ok) {     // fp16 matrix pipe, split operands (see conv2d_f16s_kernel)
         if (cls == 0) {
             for (int i = 0; i < AQ3D_MAX_GROUP; ++i) grp.p[i].nrb = 1;

@@ -87,6 +87,8 @@ CASES_F32 = [
     (64, 64, 24, 20, 3, 1, 1),
     (64, 3, 24, 20, 3, 1, 1),
     (64, 1, 17, 23, 3, 1, 1),
+    (64, 2, 188, 188, 3, 1, 1),         # the head's last convs at full size: the plain-VALU kernel (<= 4 output channels)
+    (128, 4, 35, 50, 3, 1, 1),
     (128, 256, 20, 24, 3, 2, 1),
     (512, 64, 12, 16, 3, 1, 1),
     (128, 128, 33, 31, 1, 1, 0),
