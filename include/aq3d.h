@@ -223,6 +223,7 @@ typedef struct aq3d_spconv_problem {
     const float *w_dequant, *bias, *post_scale, *post_shift, *residual;
     const int32_t *nbr, *count_out;
     float *feats_out, *absmax_out;
+    int32_t cout_real;                 /* output channels that exist when `cout` is padded (zero weight rows); 0 = all of them */
 } aq3d_spconv_problem;
 
 /* Up to 8 sparse convs of one shape (cin, cout, kvol, modes, capacities) as ONE launch — the per-branch SubMConv2d stacks of

@@ -34,6 +34,7 @@ struct SpconvArgs {
     float *feats_out;
     float *absmax_out;
     int cap_out, cin, kvol, relu;
+    int cout_real;          // output channels that exist (the rest of the padded `cout` is zero weights); 0 = all
     // static PTQ (stem kernel only): the consumer's calibrated quantiser in this epilogue — codes i8 [cap_out][cout <= 32]
     const float *next_scale;
     int8_t *next_codes;
@@ -476,6 +477,114 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
     return AQ3D_OK;
 }
 
+// ---------------------------------------------------------------- fp32 sparse conv, 128 -> 1..4 channels: plain VALU
+// VoxelNeXt's head output convs (SubMConv2d 3x3, 128 -> 1..3 channels, un-quantised: voxelnext_head.py:13-47) were padded to a
+// 16-column MFMA tile: 30 of them per frame at ~10 us each, all gather and operand staging. Here half a wave owns one output row:
+// lane l of the half holds channels 4l .. 4l+3 of the row's neighbours (one coalesced 512-byte read per kernel offset) and keeps the
+// KV x CO x 4 weights of its channels in registers for the whole launch; the CO sums are fp32 FMA chains (offset, then channel) folded
+// over the 32 lanes by a butterfly. Fixed order, fp32 throughout.
+template <int CO, int KV>
+__device__ __forceinline__ void spconv_small_body(const SpconvArgs &a, int cout_ld) {
+    constexpr int CIN = 128;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l = lane & 31;
+    int n = *a.count_out;
+    if (n > a.cap_out) n = a.cap_out;
+    const float *x = static_cast<const float *>(a.feats_in);
+    const float *w = static_cast<const float *>(a.weight);            // [KV][cout_ld][CIN]
+    f32x4 wr[KV][CO];
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+#pragma unroll
+        for (int o = 0; o < CO; ++o) wr[k][o] = *reinterpret_cast<const f32x4 *>(w + ((size_t)k * cout_ld + o) * CIN + 4 * l);
+    float bs[CO], ps[CO], pt[CO], mx[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+        bs[o] = a.bias ? a.bias[o] : 0.f;
+        ps[o] = a.post_scale ? a.post_scale[o] : 1.f;
+        pt[o] = a.post_scale ? a.post_shift[o] : 0.f;
+        mx[o] = 0.f;
+    }
+    // U row pairs per round (1x1 convs: four — a round is a chain of dependent latencies: gather-table entry, row, butterfly, store)
+    constexpr int U = KV == 1 ? 4 : 1;
+    const int nw = gridDim.x * (blockDim.x >> 6);
+    for (int r0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 2 * U; r0 < n; r0 += nw * 2 * U) {
+        int src[U][KV];
+        f32x4 xv[U][KV];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + 2 * u + half;
+#pragma unroll
+            for (int k = 0; k < KV; ++k) src[u][k] = r < n ? a.nbr[(size_t)r * KV + k] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                xv[u][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (src[u][k] >= 0) xv[u][k] = *reinterpret_cast<const f32x4 *>(x + (size_t)src[u][k] * CIN + 4 * l);
+            }
+        float acc[U][CO];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k < KV; ++k)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t = __fmaf_rn(xv[u][k][j], wr[k][o][j], t);
+                acc[u][o] = t;
+            }
+#pragma unroll
+        for (int sft = 1; sft < 32; sft <<= 1)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int o = 0; o < CO; ++o) acc[u][o] = __fadd_rn(acc[u][o], __shfl_xor(acc[u][o], sft, 64));
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + 2 * u + half;
+            if (l == 0 && r < n) {
+#pragma unroll
+                for (int o = 0; o < CO; ++o) {
+                    float v = acc[u][o];
+                    if (a.bias) v = __fadd_rn(v, bs[o]);
+                    if (a.post_scale) v = __fadd_rn(__fmul_rn(v, ps[o]), pt[o]);
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.feats_out[(size_t)r * cout_ld + o] = v;
+                    mx[o] = fmaxf(mx[o], fabsf(v));
+                }
+            }
+        }
+    }
+    if (a.absmax_out) {         // (uniform per workgroup) one atomic per workgroup and channel, and only when it would raise the value
+        __shared__ float red[4][4];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            const float m = fmaxf(mx[o], __shfl_xor(mx[o], 32, 64));       // lanes 0 and 32 hold the two halves' maxima
+            if (lane == 0) red[wave & 3][o] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < CO) {
+            const int o = threadIdx.x;
+            float m = red[0][o];
+            for (int w_ = 1; w_ < (int)(blockDim.x >> 6) && w_ < 4; ++w_) m = fmaxf(m, red[w_][o]);
+            if (m > 0.f && m > a.absmax_out[o]) aq3d_atomic_max_pos(&a.absmax_out[o], m);
+        }
+    }
+}
+template <int KV>
+__global__ __launch_bounds__(256) void spconv_small_kernel(SpconvGroup grp, int cout_ld) {
+    const SpconvArgs a = grp.p[blockIdx.y];
+    switch (a.cout_real) {      // uniform per workgroup
+    case 1: spconv_small_body<1, KV>(a, cout_ld); break;
+    case 2: spconv_small_body<2, KV>(a, cout_ld); break;
+    case 3: spconv_small_body<3, KV>(a, cout_ld); break;
+    default: spconv_small_body<4, KV>(a, cout_ld); break;
+    }
+}
+
 // ---------------------------------------------------------------- stem layer (conv_input: Cin <= 8 raw point features -> 16)
 // K = 27 * Cin is ~135: far too thin for tiles, LDS staging and barriers (the generic kernel takes 42 us for 30 k rows, all of
 // it latency). Plain VALU instead: thread = one output row x 4 output channels (blockIdx.y = channel quad, so the 4*Cin
@@ -582,7 +691,7 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
     aq3d_spconv_problem q;
     q.feats_in = feats_in; q.act_dequant = act_dequant; q.weight = weight; q.w_dequant = w_dequant; q.bias = bias;
     q.post_scale = post_scale; q.post_shift = post_shift; q.residual = residual; q.nbr = nbr; q.count_out = count_out;
-    q.feats_out = feats_out; q.absmax_out = absmax_out;
+    q.feats_out = feats_out; q.absmax_out = absmax_out; q.cout_real = 0;
     return spconv_group_impl(&q, 1, act_mode, w_mode, cap_out, cap_in, cin, cout, kvol, flags, next_scale, next_codes,
                              next_codes ? (float)((1 << (next_bits - 1)) - 1) : 0.f, stream_);
 }
@@ -612,6 +721,7 @@ static int spconv_group_impl(const aq3d_spconv_problem *probs, int32_t n, int32_
         a.bias = q.bias; a.post_scale = q.post_scale; a.post_shift = q.post_shift; a.residual = q.residual;
         a.nbr = q.nbr; a.count_out = q.count_out; a.feats_out = q.feats_out; a.absmax_out = q.absmax_out;
         a.cap_out = cap_out; a.cin = cin; a.kvol = kvol; a.relu = (flags & AQ3D_FLAG_RELU) ? 1 : 0;
+        a.cout_real = q.cout_real > 0 && q.cout_real < cout ? q.cout_real : cout;
         a.next_scale = next_scale; a.next_codes = next_codes; a.next_qmax = next_qmax;
     }
     for (int i = n; i < AQ3D_SPCONV_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
@@ -624,6 +734,15 @@ static int spconv_group_impl(const aq3d_spconv_problem *probs, int32_t n, int32_
 #undef AQ3D_STEM
         }
         AQ3D_CHECK_LAUNCH("aq3d_spconv(stem)");
+        return AQ3D_OK;
+    }
+    bool small_ok = act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && cin == 128 && (kvol == 9 || kvol == 1) && !next_codes;
+    for (int i = 0; i < n; ++i) small_ok = small_ok && grp.p[i].cout_real >= 1 && grp.p[i].cout_real <= 4 && !grp.p[i].residual;
+    if (small_ok) {         // the head's output convs: a row per half wave on the plain vector ALU (see spconv_small_kernel)
+        const dim3 grid(aq3d_grid(aq3d_div_up(cap_out, kvol == 1 ? 32 : 8), 1, 2048), n);
+        if (kvol == 9) hipLaunchKernelGGL(spconv_small_kernel<9>, grid, dim3(256), 0, stream, grp, cout);
+        else hipLaunchKernelGGL(spconv_small_kernel<1>, grid, dim3(256), 0, stream, grp, cout);
+        AQ3D_CHECK_LAUNCH("aq3d_spconv(small)");
         return AQ3D_OK;
     }
     const int cin_pad = (cin + 15) / 16 * 16;

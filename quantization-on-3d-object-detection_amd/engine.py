@@ -723,10 +723,13 @@ class Engine:
         lv = self.levels[r0["level"]]
         if G["args"] is None:
             nbr = self._nbr_of(r0["nbr"], r0["level"])
+            # the per-channel abs-max of an output is only produced for tensors some activation quantiser (or calibrator) reads: the
+            # head's output convs feed the decode, and thousands of waves updating the same few words serialise
+            read = {id(c["x"]) for c in self.sparse_convs if c["quant"] is not None}
             G["args"] = ops.spconv_problems([dict(
                 feats_in=r["x"]["buf"], weight=r["weight"], w_dequant=r["w_dequant"], bias=r["bias"], post_scale=r["post_scale"],
                 post_shift=r["post_shift"], nbr=nbr, count_out=lv["count"], feats_out=r["out"]["buf"],
-                absmax_out=self.arena.view(r["out"]["amax"])) for r in recs])
+                absmax_out=self.arena.view(r["out"]["amax"]) if id(r["out"]) in read else None, cout_real=r["cout_real"]) for r in recs])
             G["w_mode"] = ops.W_I8 if r0["weight"].dtype == torch.int8 else ops.W_F32
         with _Timed(self, "spconv_c%d" % r0["cout"]):
             ops.spconv_group(G["args"], ops.ACT_F32, G["w_mode"], lv["cap"], self.levels[r0["x"]["level"]]["cap"], r0["cin"], r0["cout"],

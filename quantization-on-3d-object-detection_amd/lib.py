@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class Aq3dError(RuntimeError):
@@ -54,7 +54,7 @@ class Conv2dProblem(Structure):
 class SpconvProblem(Structure):
     _fields_ = [("feats_in", c_void_p), ("act_dequant", c_void_p), ("weight", c_void_p), ("w_dequant", c_void_p),
                 ("bias", c_void_p), ("post_scale", c_void_p), ("post_shift", c_void_p), ("residual", c_void_p),
-                ("nbr", c_void_p), ("count_out", c_void_p), ("feats_out", c_void_p), ("absmax_out", c_void_p)]
+                ("nbr", c_void_p), ("count_out", c_void_p), ("feats_out", c_void_p), ("absmax_out", c_void_p), ("cout_real", c_int32)]
 
 
 class Level(Structure):

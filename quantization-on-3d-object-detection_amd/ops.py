@@ -323,12 +323,13 @@ def spconv_coded(codes, wprep, out_mul, nbr, count_out, *, bias=None, post_scale
 
 def spconv_problems(recs):
     """ctypes array of aq3d_spconv_problem from dicts(feats_in, act_dequant, weight, w_dequant, bias, post_scale, post_shift,
-    residual, nbr, count_out, feats_out, absmax_out)."""
+    residual, nbr, count_out, feats_out, absmax_out, cout_real)."""
     arr = (_lib.SpconvProblem * len(recs))()
     for q, r in zip(arr, recs):
         for k in ("feats_in", "act_dequant", "weight", "w_dequant", "bias", "post_scale", "post_shift", "residual", "nbr",
                   "count_out", "feats_out", "absmax_out"):
             setattr(q, k, _addr(r.get(k)))
+        q.cout_real = int(r.get("cout_real") or 0)
     return arr
 
 

@@ -270,6 +270,53 @@ def test_spconv_f32_small_and_large_magnitudes(dev, cout, scale):
     assert err <= 2e-6, err
 
 
+@pytest.mark.parametrize("ksize", [(1, 3, 3), (1, 1, 1)])
+def test_spconv_group_small_outputs(dev, ksize):
+    """VoxelNeXt's head output convs: a group of 128 -> 1..4 channel fp32 sparse convs whose weights are padded to 16 rows. With
+    cout_real the group runs on the plain-VALU kernel (a row per half wave); without it, on the matrix pipe. Both against float64."""
+    from amdq3d import ops
+    cin, cpad = 128, 16
+    kvol = int(np.prod(ksize))
+    idx, shape = _sparse_input(dev, m_pts=3000, seed=11, batch=1)
+    idx[:, 1] = 0
+    idx = np.unique(idx, axis=0)
+    shape = [1, shape[1], shape[2]]
+    m = len(idx)
+    rng = np.random.default_rng(21)
+    nbr_ref = OS.subm_neighbors(idx, shape, ksize)
+    cap = m + 13
+    nbr = torch.full((cap, kvol), -1, dtype=torch.int32, device=dev)
+    nbr[:m] = torch.from_numpy(nbr_ref).to(dev)
+    count = torch.tensor([m], dtype=torch.int32, device=dev)
+    recs, refs = [], []
+    for cout in (1, 2, 3, 4, 3):
+        feats = rng.normal(0, 1, (m, cin)).astype(np.float32)
+        w = (rng.normal(0, 1, (cout, kvol, cin)) / np.sqrt(kvol * cin)).astype(np.float32)
+        bias = rng.normal(0, 0.1, cout).astype(np.float32)
+        ref = np.zeros((m, cout), np.float64)
+        for k in range(kvol):
+            hit = nbr_ref[:, k] >= 0
+            ref[hit] += feats[nbr_ref[hit, k]].astype(np.float64) @ w[:, k, :].astype(np.float64).T
+        refs.append(ref + bias)
+        wp = np.zeros((kvol, cpad, cin), np.float32)
+        wp[:, :cout] = w.transpose(1, 0, 2)
+        bp = np.zeros((cpad,), np.float32); bp[:cout] = bias
+        fin = torch.zeros((cap, cin), device=dev); fin[:m] = torch.from_numpy(feats).to(dev)
+        recs.append(dict(feats_in=fin, weight=torch.from_numpy(wp).to(dev), bias=torch.from_numpy(bp).to(dev), nbr=nbr, count_out=count,
+                         feats_out=torch.zeros((cap, cpad), device=dev), absmax_out=torch.zeros((cpad,), device=dev), cout_real=cout))
+    for small in (True, False):
+        for r in recs:
+            r["feats_out"].zero_(); r["absmax_out"].zero_()
+        args = ops.spconv_problems([dict(r, cout_real=r["cout_real"] if small else 0) for r in recs])
+        ops.spconv_group(args, ops.ACT_F32, ops.W_F32, cap, cap, cin, cpad, kvol, relu=False)
+        for r, ref in zip(recs, refs):
+            co = r["cout_real"]
+            y = r["feats_out"][:m, :co].cpu().numpy().astype(np.float64)
+            assert np.abs(y - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (small, co)
+            np.testing.assert_array_equal(r["absmax_out"][:co].cpu().numpy(), np.abs(r["feats_out"][:m, :co].cpu().numpy()).max(axis=0))
+            assert float(r["feats_out"][m:].abs().max()) == 0.0           # rows past the live count untouched
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (128, 128)])
 def test_spconv_int8_codes(dev, cin, cout):
     """QConvNd semantics: per-column activation codes (scale folded into the gather) x per-out-channel weight codes."""
