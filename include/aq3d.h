@@ -186,7 +186,9 @@ enum {
 };
 enum {
     AQ3D_W_F32 = 0,    /* weight is f32 [kvol, Cout, Cin]                           */
-    AQ3D_W_I8 = 1      /* weight is i8 codes [kvol, Cout, Cin]; value = code * w_dequant[cout] */
+    AQ3D_W_I8 = 1,     /* weight is i8 codes [kvol, Cout, Cin]; value = code * w_dequant[cout] */
+    AQ3D_W_F16S = 2    /* fp32 weights already split into fp16 planes, f16 [kvol * Cout, 2, Cin] (aq3d_conv2d_split_weight of the f32
+                        * [kvol * Cout, Cin] matrix): f32 activations, Cin = 128, Cout = 128 or 16 only */
 };
 enum {
     AQ3D_FLAG_RELU = 1,

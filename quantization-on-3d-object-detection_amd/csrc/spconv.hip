@@ -249,7 +249,10 @@ typedef _Float16 sp_f16x4 __attribute__((ext_vector_type(4)));
 // W32: fp32 weights (an un-quantised layer), split into fp16 hi | lo planes while staged, three MFMAs per product like
 // conv2d_f16s_kernel (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo; the lo*lo term, ~2^-22 relative, is dropped). The fp32 matrix pipe
 // (spconv_kernel) took 242 us for VoxelNeXt's one 128 -> 128 fp32 layer.
-template <int CIN, int COUT, int WR, int WC, bool W32 = false>
+// WSPLIT (with W32): the fp32 weights arrive already split, f16 [kvol][Cout][2][Cin] (aq3d_conv2d_split_weight; w_mode AQ3D_W_F16S) — the
+// split is the same for every row tile and kernel offset, and a 128 x 128 fp32 tile split by 256 threads per offset was most of the
+// un-quantised 128 -> 128 layer's 180 us.
+template <int CIN, int COUT, int WR, int WC, bool W32 = false, bool WSPLIT = false>
 __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
     const SpconvArgs a = grp.p[blockIdx.y];
     constexpr int TM = 16 * WR;
@@ -308,7 +311,16 @@ __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
                 *reinterpret_cast<sp_f16x4 *>(Ah + r * LDH + c4 * 4) = h;
                 *reinterpret_cast<sp_f16x4 *>(Al + r * LDH + c4 * 4) = l;
             }
-            if (W32) {
+            if (W32 && WSPLIT) {
+                constexpr int C8 = CIN / 8;
+                const _Float16 *wk16 = static_cast<const _Float16 *>(a.weight) + (size_t)k * COUT * 2 * CIN;
+                for (int t = tid; t < COUT * C8; t += 256) {
+                    const int o = t / C8, c8 = t - o * C8;
+                    *reinterpret_cast<sp_f16x8 *>(Bh + o * LDH + c8 * 8) = *reinterpret_cast<const sp_f16x8 *>(wk16 + (size_t)(o * 2) * CIN + c8 * 8);
+                    *reinterpret_cast<sp_f16x8 *>(Bl + o * LDH + c8 * 8) = *reinterpret_cast<const sp_f16x8 *>(wk16 + (size_t)(o * 2 + 1) * CIN + c8 * 8);
+                }
+            }
+            if (W32 && !WSPLIT) {
                 const float *wk32 = static_cast<const float *>(a.weight) + (size_t)k * COUT * CIN;
                 for (int t = tid; t < COUT * C4; t += 256) {
                     const int o = t / C4, c4 = t - o * C4;
@@ -452,7 +464,7 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
         }
     }
     if constexpr (CIN_PAD == 128 && (COUT == 128 || COUT == 16)) {
-        if (act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && a.cin == CIN_PAD) {      // un-quantised 128 -> 128 / 128 -> 16 layers: fp16 pipe, split operands
+        if (act_mode == AQ3D_ACT_F32 && (w_mode == AQ3D_W_F32 || w_mode == AQ3D_W_F16S) && a.cin == CIN_PAD) {      // un-quantised 128 -> 128 / 128 -> 16 layers: fp16 pipe, split operands
             bool same = true;
             for (int i = 1; i < n; ++i) same = same && grp.p[i].cin == CIN_PAD;
             if (same) {
@@ -460,9 +472,15 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
                 constexpr size_t lds3 = (size_t)(2 * TM2 + 2 * COUT) * (CIN_PAD + 8) * 2 + (size_t)TM2 * 27 * 4 + (size_t)4 * COUT * 4;
                 const int tiles2 = aq3d_div_up(a.cap_out, TM2);
                 const int grid2 = tiles2 < 2048 ? (tiles2 < 1 ? 1 : tiles2) : 2048;
-                auto kern = spconv_f16w_kernel<CIN_PAD, COUT, 4, 1, true>;
-                hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-                hipLaunchKernelGGL(kern, dim3(grid2, n), dim3(256), lds3, stream, grp);
+                if (w_mode == AQ3D_W_F16S) {
+                    auto kern = spconv_f16w_kernel<CIN_PAD, COUT, 4, 1, true, true>;
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                    hipLaunchKernelGGL(kern, dim3(grid2, n), dim3(256), lds3, stream, grp);
+                } else {
+                    auto kern = spconv_f16w_kernel<CIN_PAD, COUT, 4, 1, true>;
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                    hipLaunchKernelGGL(kern, dim3(grid2, n), dim3(256), lds3, stream, grp);
+                }
                 AQ3D_CHECK_LAUNCH("aq3d_spconv");
                 return AQ3D_OK;
             }
@@ -716,6 +734,8 @@ static int spconv_group_impl(const aq3d_spconv_problem *probs, int32_t n, int32_
         AQ3D_REQUIRE(act_mode != AQ3D_ACT_I8 || ((cin % 16) == 0 && q.act_dequant), "aq3d_spconv: int8 activations need cin%%16==0 and act_dequant");
         AQ3D_REQUIRE(w_mode != AQ3D_W_I8 || ((cin % 16) == 0 && q.w_dequant), "aq3d_spconv: int8 weights need cin%%16==0 and w_dequant");
         AQ3D_REQUIRE((q.post_scale == nullptr) == (q.post_shift == nullptr), "aq3d_spconv: post_scale/post_shift must come together");
+        AQ3D_REQUIRE(w_mode != AQ3D_W_F16S || (act_mode == AQ3D_ACT_F32 && cin == 128 && (cout == 128 || cout == 16)),
+                     "aq3d_spconv: pre-split fp16 weight planes are taken for f32 activations, cin = 128, cout = 128 | 16 only");
         SpconvArgs &a = grp.p[i];
         a.feats_in = q.feats_in; a.act_dequant = q.act_dequant; a.weight = q.weight; a.w_dequant = q.w_dequant;
         a.bias = q.bias; a.post_scale = q.post_scale; a.post_shift = q.post_shift; a.residual = q.residual;

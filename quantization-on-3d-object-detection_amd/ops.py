@@ -250,7 +250,7 @@ def quantize_rows(x, amax, count, bits=8, per_tensor=False, want_codes=True, wan
 
 
 ACT_F32, ACT_I8 = 0, 1
-W_F32, W_I8 = 0, 1
+W_F32, W_I8, W_F16S = 0, 1, 2
 FLAG_RELU, FLAG_SKIP_F32, FLAG_W16 = 1, 2, 4
 
 
@@ -261,9 +261,9 @@ def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequan
     L = _lib.load()
     cap_out, kvol = nbr.shape
     act_mode = ACT_I8 if feats_in.dtype == torch.int8 else ACT_F32
-    w_mode = W_I8 if weight.dtype == torch.int8 else W_F32
+    w_mode = W_I8 if weight.dtype == torch.int8 else (W_F16S if weight.dtype == torch.float16 else W_F32)
     cin = feats_in.shape[1]
-    assert weight.shape == (kvol, cout, cin), (tuple(weight.shape), (kvol, cout, cin))
+    assert weight.shape == ((kvol * cout, 2, cin) if w_mode == W_F16S else (kvol, cout, cin)), (tuple(weight.shape), (kvol, cout, cin))
     y = out if out is not None else torch.empty((cap_out, cout), dtype=f32, device=nbr.device)
     check(L.aq3d_spconv(_p(feats_in), act_mode, _p(act_dequant), _p(weight), w_mode, _p(w_dequant), _p(bias),
                         _p(post_scale), _p(post_shift), _p(residual), _p(nbr), _p(count_out), cap_out, int(feats_in.shape[0]),
