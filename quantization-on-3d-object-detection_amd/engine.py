@@ -728,7 +728,7 @@ class Engine:
             nbr = self._nbr_of(r0["nbr"], r0["level"])
             # the per-channel abs-max of an output is only produced for tensors some activation quantiser (or calibrator) reads: the
             # head's output convs feed the decode, and thousands of waves updating the same few words serialise
-            read = {id(c["x"]) for c in self.sparse_convs if c["quant"] is not None}
+            read = self._amax_readers()
             G["args"] = ops.spconv_problems([dict(
                 feats_in=r["x"]["buf"], weight=r["weight"], w_dequant=r["w_dequant"], bias=r["bias"], post_scale=r["post_scale"],
                 post_shift=r["post_shift"], nbr=nbr, count_out=lv["count"], feats_out=r["out"]["buf"],
@@ -967,6 +967,15 @@ class Engine:
             others = [u for u in users.get(id(p["out"]), []) if u is not r]
             p["skip_f32"] = bool(p.get("coded")) and not others and id(p["out"]) not in pinned and not keep_f32
 
+    def _amax_readers(self):
+        """ids of the sparse tensors whose per-channel abs-max some activation quantiser / calibrator reads."""
+        if getattr(self, "_amax_read", None) is None or self._amax_read[0] != len(self.sparse_convs):
+            self._amax_read = (len(self.sparse_convs), {id(c["x"]) for c in self.sparse_convs if c["quant"] is not None})
+        return self._amax_read[1]
+
+    def _amax_out(self, out):
+        return self.arena.view(out["amax"]) if id(out) in self._amax_readers() else None
+
     def _run_spconv(self, rec):
         lv = self.levels[rec["level"]]
         x = rec["x"]
@@ -997,7 +1006,7 @@ class Engine:
                     ops.spconv_coded(rec["codes"], rec["wprep"], rec["out_mul"], nbr, lv["count"], bias=rec["bias"],
                                      post_scale=rec["post_scale"], post_shift=rec["post_shift"],
                                      residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
-                                     absmax_out=self.arena.view(out["amax"]), out=out["buf"],
+                                     absmax_out=self._amax_out(out), out=out["buf"],
                                      next_scale=None if nx is None else nx["scale"], next_codes=None if nx is None else nx["codes"],
                                      next_bits=8 if nx is None else nx["bits"], skip_f32=bool(rec.get("skip_f32")),
                                      w16=self.sparse_w16)
@@ -1014,7 +1023,7 @@ class Engine:
             ops.spconv(feats, rec["weight"], nbr, lv["count"], rec["cout"], act_dequant=act_dq, w_dequant=rec["w_dequant"],
                        bias=rec["bias"], post_scale=rec["post_scale"], post_shift=rec["post_shift"],
                        residual=None if rec["residual"] is None else rec["residual"]["buf"], relu=rec["relu"],
-                       absmax_out=self.arena.view(out["amax"]), out=out["buf"],
+                       absmax_out=self._amax_out(out), out=out["buf"],
                        next_scale=None if nx is None else nx["scale"], next_codes=None if nx is None else nx["codes"],
                        next_bits=8 if nx is None else nx["bits"])
 
