@@ -89,6 +89,7 @@ CASES_F32 = [
     (64, 1, 17, 23, 3, 1, 1),
     (64, 2, 188, 188, 3, 1, 1),         # the head's last convs at full size: the plain-VALU kernel (<= 4 output channels)
     (128, 4, 35, 50, 3, 1, 1),
+    (16, 3, 5, 7, 3, 1, 1),             # one channel chunk, an image smaller than a tile
     (128, 256, 20, 24, 3, 2, 1),
     (512, 64, 12, 16, 3, 1, 1),
     (128, 128, 33, 31, 1, 1, 0),

@@ -315,6 +315,16 @@ def test_spconv_group_small_outputs(dev, ksize):
             assert np.abs(y - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (small, co)
             np.testing.assert_array_equal(r["absmax_out"][:co].cpu().numpy(), np.abs(r["feats_out"][:m, :co].cpu().numpy()).max(axis=0))
             assert float(r["feats_out"][m:].abs().max()) == 0.0           # rows past the live count untouched
+    # one live row / none: nothing beyond it is written
+    for live in (1, 0):
+        count.fill_(live)
+        for r in recs:
+            r["feats_out"].zero_()
+        ops.spconv_group(ops.spconv_problems(recs), ops.ACT_F32, ops.W_F32, cap, cap, cin, cpad, kvol, relu=False)
+        for r, ref in zip(recs, refs):
+            assert float(r["feats_out"][live:].abs().max()) == 0.0
+            if live:
+                assert np.isfinite(r["feats_out"][0].cpu().numpy()).all()
 
 
 @pytest.mark.parametrize("cin,cout", [(16, 16), (32, 64), (128, 128)])
