@@ -21,6 +21,26 @@ def small_cfg(kind="waymo", half_range=12.8):
     return cfg
 
 
+def calibrate_hm_with_oracle(model, cfg, points, fraction=0.001):
+    """The heat-map branch's BatchNorm statistics (amdq3d.synthetic.calibrate_heat_map) from one fp32 forward of the CPU oracle:
+    the tests' route to the hidden hm activations (bench.py and tools/eval.py take them from the device engine)."""
+    from amdq3d.synthetic import calibrate_heat_map, hm_hidden_paths
+    state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    tr = {}
+    if cfg.MODEL.NAME == "VoxelNeXt":
+        from oracle import voxelnext as OV
+        OV.run(state, cfg, points, None, trace=tr)
+    else:
+        from oracle import centerpoint as OC
+        OC.run(state, cfg, points, None, trace=tr)
+    hidden = {}
+    for path in hm_hidden_paths(model):
+        t = tr[path]
+        t = t.numpy() if hasattr(t, "numpy") else np.asarray(t)
+        hidden[path] = np.moveaxis(t, 1, -1).reshape(-1, t.shape[1]) if t.ndim == 4 else t
+    return calibrate_heat_map(model, hidden, fraction=fraction)
+
+
 def build_model(cfg, n_points, n_voxels, n_frames=2, seed=4):
     from amdq3d.datasets import SyntheticDataset
     from amdq3d.detector import build_network
@@ -29,6 +49,10 @@ def build_model(cfg, n_points, n_voxels, n_frames=2, seed=4):
     model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
     init_synthetic_weights(model, seed)
     model.eval()
+    cal = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_frames=1, n_points=n_points, n_voxels=n_voxels, seed0=1000 + seed)
+    # a frame that is not among the test's own; the small test ranges (BEV 32 x 32 .. 40 x 40) get a larger firing fraction so that
+    # every frame has tens of boxes to compare
+    calibrate_hm_with_oracle(model, cfg, cal[0]["points"], fraction=0.001 if n_voxels >= 15000 else 0.005)
     model.sparse_w16 = False          # tests hold the layers to the 2e-5 bar: 24-bit weight planes (the product default is 16-bit,
     return ds, model                  # covered by its own tests at its own bar)
 

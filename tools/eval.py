@@ -155,7 +155,7 @@ def main(argv=None):
     from amdq3d.config import AttrDict, cfg_from_yaml_file
     from amdq3d.datasets import FrameFileDataset, SyntheticDataset
     from amdq3d.detector import build_network
-    from amdq3d.synthetic import init_synthetic_weights
+    from amdq3d.synthetic import calibrate_heat_map_on_device, init_synthetic_weights
     logging.basicConfig(level=logging.INFO, format="%(asctime)s  %(levelname)5s  %(message)s")
     logger = logging.getLogger("eval")
     cfg = cfg_from_yaml_file(os.path.join(ROOT, args.cfg_file) if not os.path.isabs(args.cfg_file) else args.cfg_file, AttrDict())
@@ -178,8 +178,16 @@ def main(argv=None):
     if args.ckpt:
         model.load_params_from_file(filename=args.ckpt, logger=logger, to_cpu=True)
     else:
-        logger.info("no --ckpt: seeded synthetic weights")
+        logger.info("no --ckpt: seeded synthetic weights; heat-map statistics from one calibration frame run on the device")
         init_synthetic_weights(model, 4)
+        model.eval()
+        model.cuda()
+        cal = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_frames=1, n_points=args.points, n_voxels=args.voxels, seed0=1004) \
+            if not args.frames else dataset
+        from amdq3d.datasets import load_data_to_gpu
+        cb = cal.collate_batch([cal[0]])
+        load_data_to_gpu(cb, device)
+        calibrate_heat_map_on_device(model, cb)
     model.eval()
     if args.quant != "none":
         if cfg.MODEL.NAME == "VoxelNeXt":
