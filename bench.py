@@ -365,7 +365,7 @@ def oracle_runs(cfg, ds, state, n_frames, n_floor, cache):
     return cache
 
 
-def accuracy_proxy(cfg, ds, state, model, batches, n_frames, cache, n_floor=2):
+def accuracy_proxy(cfg, ds, state, model, batches, n_frames, cache, n_floor=4):
     """SURVEY §8c, last row — the offline stand-in for "mAP delta vs fp32 ref", WITH its yardsticks, on the same
     seeded frames and weights. Per comparison: `pseudo_ap` (average precision with the reference run's boxes scoring >= 0.3 as
     ground truth, BEV IoU 0.7, same label; a run against itself = 1.0), and recall / precision of matched boxes for all boxes and
@@ -380,6 +380,7 @@ def accuracy_proxy(cfg, ds, state, model, batches, n_frames, cache, n_floor=2):
     implementation adds on top (AP of (i) - AP of (iii)), in AP points of the synthetic model (planted-peak heat map, box priors:
     amdq3d/synthetic.py). Reported as a proxy, never as mAP."""
     t0 = time.time()
+    n_floor = min(n_floor, n_frames)
     oracle_runs(cfg, ds, state, n_frames, n_floor, cache)
     dets = []
     for i in range(n_frames):

@@ -1,0 +1,114 @@
+"""Box-level agreement of the FREE-RUNNING int8 engine with the int8 oracle at BASELINE size: the whole network,
+no teacher forcing, on the synthetic model with a planted-peak heat map and box priors (amdq3d/synthetic.py).
+
+A dynamically quantised network turns fp32 summation-order noise into different int8 codes, so two CORRECT int8 runs do not produce
+the same boxes; how far apart they are is measured here by the oracle against itself with float64 accumulation (the floor). The
+engine has to agree with the oracle as well as that, within BAR, in both weight-plane modes of the quantised sparse convs and under
+static PTQ (quant/quant_centerpoint.py:127-129). Metrics (bench.py): pseudo-AP (the reference run's boxes scoring >= 0.3 as ground
+truth, BEV IoU 0.7, same label; a run against itself = 1.0) and the recall of the boxes scoring >= 0.3.
+"""
+import numpy as np
+import pytest
+import torch
+
+import bench
+from helpers import build_model
+from oracle import centerpoint as OC
+from oracle import sparse as OS
+
+pytestmark = pytest.mark.gpu
+
+N_FRAMES = 2
+BAR = 0.03          # engine-vs-oracle may be this much below oracle-vs-oracle (AP and recall are fractions of ~150 .. 350 boxes)
+
+
+def _full_cfg():
+    from amdq3d.config import AttrDict, cfg_from_yaml_file
+    return cfg_from_yaml_file("cfgs/waymo_models/centerpoint.yaml", AttrDict())
+
+
+def _oracle(state, cfg, ds, recipe, f64=False):
+    OS.ACCUM_DTYPE = np.float64 if f64 else np.float32
+    try:
+        return [OC.run(state, cfg, ds[i]["points"], recipe) for i in range(N_FRAMES)]
+    finally:
+        OS.ACCUM_DTYPE = np.float32
+
+
+def _engine(model, ds, dev):
+    from amdq3d.datasets import load_data_to_gpu
+    out = []
+    for i in range(N_FRAMES):
+        b = ds.collate_batch([ds[i]])
+        load_data_to_gpu(b, dev)
+        with torch.no_grad():
+            p = model(b)[0][0]
+        out.append((p["pred_boxes"].cpu().numpy(), p["pred_scores"].cpu().numpy(), p["pred_labels"].cpu().numpy()))
+    return out
+
+
+def _cmp(ref, det):
+    pairs = list(zip(ref, det))
+    return bench._pseudo_ap(pairs, 0.3), bench._agg(pairs, 0.3)["recall"], bench._agg(pairs)["recall"]
+
+
+@pytest.fixture(scope="module")
+def w150k(dev):
+    cfg = _full_cfg()
+    ds, model = build_model(cfg, n_points=150000, n_voxels=30000, n_frames=4)
+    model.voxel_capacity = 40960
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    return dict(cfg=cfg, ds=ds, model=model, state=state)
+
+
+def test_free_running_int8_boxes_agree_with_the_oracle_as_well_as_the_oracle_with_itself(dev, w150k):
+    from amdq3d import quant as Qz
+    cfg, ds, model, state = (w150k[k] for k in ("cfg", "ds", "model", "state"))
+    rec = OC.Recipe(8, 8, True, 0.5)
+    fp32 = _oracle(state, cfg, ds, None)
+    int8 = _oracle(state, cfg, ds, rec)
+    int8_64 = _oracle(state, cfg, ds, rec, f64=True)
+    assert min(len(r[1]) for r in fp32) > 50
+    floor = _cmp(int8, int8_64)
+    recipe = _cmp(fp32, int8)
+    print("\nW150k, %d frames, boxes per frame (fp32 oracle): %s" % (N_FRAMES, [len(r[1]) for r in fp32]))
+    print("  (i)  oracle int8 vs oracle fp32            : AP %.4f  recall(>=0.3) %.4f  recall(all) %.4f" % recipe)
+    print("  (iv) oracle int8 f64-acc vs oracle int8    : AP %.4f  recall(>=0.3) %.4f  recall(all) %.4f   <- the floor" % floor)
+    assert floor[0] >= 0.9 and floor[1] >= 0.9, "the synthetic model's heat map no longer separates peaks from background"
+    Qz.quant(model, 8, 8, sq=True, alpha=0.5, static=False)
+    model.cuda()
+    for w16 in (False, True):
+        model.sparse_w16 = w16
+        model.invalidate_engine()
+        det = _engine(model, ds, dev)
+        assert model.engine().sparse_w16 == w16
+        got, vs_fp32 = _cmp(int8, det), _cmp(fp32, det)
+        print("  (ii) engine int8 (%s planes) vs oracle int8 : AP %.4f  recall(>=0.3) %.4f  recall(all) %.4f" % (("16-bit" if w16 else "24-bit",) + got))
+        print("  (iii) engine int8 (%s planes) vs oracle fp32: AP %.4f  recall(>=0.3) %.4f  recall(all) %.4f" % (("16-bit" if w16 else "24-bit",) + vs_fp32))
+        assert got[0] >= floor[0] - BAR and got[1] >= floor[1] - BAR, "engine int8 is further from the int8 oracle than the oracle from itself"
+        assert vs_fp32[0] >= recipe[0] - BAR and vs_fp32[1] >= recipe[1] - BAR, "engine int8 loses more against fp32 than the recipe does"
+    model.sparse_w16 = False
+
+
+def test_free_running_static_ptq_boxes(dev):
+    """The same under static PTQ: amax calibrated on frames 2, 3 (device) / by oracle.calibrate, frames 0, 1 compared."""
+    from amdq3d import quant as Qz
+    cfg = _full_cfg()
+    ds, model = build_model(cfg, n_points=150000, n_voxels=30000, n_frames=4)
+    model.voxel_capacity = 40960
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.cuda()
+    loader = [ds.collate_batch([ds[i]]) for i in (2, 3)]
+    Qz.quant(model, 8, 8, sq=True, alpha=0.5, static=True, test_loader=loader, n_batches=2)
+    static = OC.calibrate(state, cfg, [ds[i]["points"] for i in (2, 3)], OC.Recipe(8, 8, True, 0.5))
+    rec = OC.Recipe(8, 8, True, 0.5, static=static)
+    int8 = _oracle(state, cfg, ds, rec)
+    int8_64 = _oracle(state, cfg, ds, rec, f64=True)
+    floor = _cmp(int8, int8_64)
+    print("\nW150k static PTQ: (iv) oracle f64-acc vs oracle: AP %.4f  recall(>=0.3) %.4f  recall(all) %.4f" % floor)
+    for w16 in (False, True):
+        model.sparse_w16 = w16
+        model.invalidate_engine()
+        got = _cmp(int8, _engine(model, ds, dev))
+        print("  (ii) engine static int8 (%s planes) vs oracle: AP %.4f  recall(>=0.3) %.4f  recall(all) %.4f" % (("16-bit" if w16 else "24-bit",) + got))
+        assert got[0] >= floor[0] - BAR and got[1] >= floor[1] - BAR
