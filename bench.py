@@ -425,6 +425,8 @@ def cpu_baseline_from_cache(cache, n_points):
     busy = sum(cpu) / max(sum(wall), 1e-9)
     return {"value": 1.0 / med, "unit": "frames/s", "cores": max(1, int(round(busy))), "threads_configured": int(torch.get_num_threads()),
             "cores_busy_avg": round(busy, 2), "kind": "port",
+            "note": "single-thread-bound numpy port of the reference's CPU path: gather loops set the pace, BLAS worker threads idle-spin "
+                    "(12.1 s/frame at 128 threads, 11.9 s at 1: profiles/r02/cpu_baseline_protocol.json); `cores` = process CPU time / wall time",
             "sample": "1 warm-up + %d timed frames (%d pts) through %s, median %.1f s/frame (all: %s)"
                       % (len(wall), n_points, cache.get("name"), med, ", ".join("%.1f" % v for v in wall))}
 
@@ -441,9 +443,10 @@ def main():
     ap.add_argument("--workload", default="centerpoint", choices=sorted(WORKLOADS))
     ap.add_argument("--static", action="store_true", help="static PTQ (calibrated amax, quant_centerpoint.py:127-129) instead of the "
                     "dynamic recipe: the sparse quantisers run in producer epilogues, no per-frame quantiser launches")
-    ap.add_argument("--sparse-w24", action="store_true", help="quantised sparse convs multiply by 24-bit fixed-point weights (three int8 "
-                    "planes, layers within 2e-5 of the oracle) instead of the product default, 16-bit ones (AQ3D_FLAG_W16: two planes, layers "
-                    "within 1e-3 of their output scale, measured ~5e-5); the default run reports the other mode beside `value`")
+    ap.add_argument("--sparse-w16", action="store_true", help="quantised sparse convs multiply by 16-bit fixed-point weights (AQ3D_FLAG_W16: "
+                    "two int8 planes, layers within 1e-3 of their output scale, measured <= 1e-4) instead of the product default, 24-bit ones "
+                    "(three planes, layers within 2e-5 of the oracle: the mode the test suite pins); the default run reports the other "
+                    "mode beside `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="timed frames of a SEPARATE CPU-baseline run; 0 (default): the int8 oracle "
@@ -467,7 +470,7 @@ def main():
     lib.load()
     cfg_path, n_points, n_voxels, wl_desc = WORKLOADS[args.workload]
     cfg, ds, model, state = build(cfg_path, dev, n_points, n_voxels, seed0=rank_seed0(rank), static=args.static)
-    model.sparse_w16 = not args.sparse_w24
+    model.sparse_w16 = bool(args.sparse_w16)
     model.invalidate_engine()       # (the static recipe's calibration forwards have already compiled a plan)
 
     # N_FRAMES distinct frames per rank, resident in HBM before the timed region (also kept in pinned host memory for the
@@ -588,7 +591,7 @@ def main():
                        "voxels": n_voxels, "parallelism": "replicas(frames)x%d" % world, "world_size_seen_by_rccl": world_seen,
                        "avg_boxes_per_frame": n_det / max(args.steps, 1),
                        "row_capacity_per_index_level": [lv["cap"] for lv in eng.levels],
-                       "sparse_conv_weights": "16-bit fixed point, two int8 planes (layers <= 1e-3 of scale)" if not args.sparse_w24
+                       "sparse_conv_weights": "16-bit fixed point, two int8 planes (layers <= 1e-3 of scale)" if args.sparse_w16
                        else "24-bit fixed point, three int8 planes (layers <= 2e-5 of scale)"},
             "roofline": roof,
             "roofline_by_kernel": by_kernel,
@@ -620,7 +623,7 @@ def main():
         if world == 1 and not args.no_accuracy:
             # the other precision of the quantised sparse convs, same pipeline, same frames (a second plan): reported beside `value`,
             # never as `value`
-            other = bool(args.sparse_w24)
+            other = not args.sparse_w16
             try:
                 model.sparse_w16 = other
                 model.invalidate_engine()
@@ -640,7 +643,7 @@ def main():
                     "accuracy": accuracy_proxy(cfg, ds, state, model, batches, n_acc, cache)}
             except Exception as e:
                 out["value_sparse_w16" if other else "value_sparse_w24"] = {"failed": repr(e)}
-            model.sparse_w16 = not args.sparse_w24
+            model.sparse_w16 = bool(args.sparse_w16)
             model.invalidate_engine()
         if world == 1 and not args.no_cpu_baseline:
             try:

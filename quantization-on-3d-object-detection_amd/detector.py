@@ -48,12 +48,14 @@ class Detector3DTemplate(nn.Module):
         self.level_capacity_factor = 4.0
         self.level_capacity = None
         self.voxelize_on_device = True   # False: consume batch_dict['voxels'/'voxel_coords'] when present
-        # quantised sparse convs (int8 codes x fixed-point weight planes on the int8 matrix pipe): True (default) = 16-bit weights (two
-        # int8 planes: <= 2^-9 per weight on a +-127 scale, every layer within 1e-3 of its output scale — measured ~5e-5 — i.e. more
-        # than the north star's "int8 weights x fp16 activations"); False = 24-bit weights (three planes, fp32-grade sums, every layer
-        # within 2e-5 of the oracle, 1.5x the matrix work). bench.py's accuracy legs show the two indistinguishable at box level
-        # (both sit at the model's own summation-order noise floor). Set before the first forward (or call invalidate_engine()).
-        self.sparse_w16 = True
+        # quantised sparse convs (int8 codes x fixed-point weight planes on the int8 matrix pipe): False (default) = 24-bit weights
+        # (three int8 planes, fp32-grade sums, every layer within 2e-5 of the oracle); True = 16-bit weights (two planes: <= 2^-9 per
+        # weight on a +-127 scale, every layer within 1e-3 of its output scale, measured <= 1e-4; 2/3 of the matrix work, ~6 % more
+        # frames/s). Box level at BASELINE size (round 4, planted-peak model): 24-bit agrees with the int8 oracle
+        # better than the oracle with itself under float64 accumulation (AP 0.96 vs 0.94), 16-bit 2-3 AP points worse (0.93) and
+        # ~1 AP point worse against the fp32 oracle — a 1e-4 layer error flips int8 codes a 1e-6 one does not. Set before the first
+        # forward (or call invalidate_engine()).
+        self.sparse_w16 = False
 
     @property
     def mode(self):

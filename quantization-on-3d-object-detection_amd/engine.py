@@ -142,7 +142,7 @@ class Engine:
         self.arena = _Arena(device)
         self.steps = []
         self.tensors = {}
-        self.sparse_w16 = bool(getattr(det, "sparse_w16", True))
+        self.sparse_w16 = bool(getattr(det, "sparse_w16", False))
         self._head_args = {}
         self._force_rows = False     # teacher-forced tests: run the rows-only quantiser even where a producer epilogue does it
         if isinstance(det.backbone_3d, VoxelResBackBone8xVoxelNeXt):

@@ -53,8 +53,7 @@ def build_model(cfg, n_points, n_voxels, n_frames=2, seed=4):
     # a frame that is not among the test's own; the small test ranges (BEV 32 x 32 .. 40 x 40) get a larger firing fraction so that
     # every frame has tens of boxes to compare
     calibrate_hm_with_oracle(model, cfg, cal[0]["points"], fraction=0.001 if n_voxels >= 15000 else 0.005)
-    model.sparse_w16 = False          # tests hold the layers to the 2e-5 bar: 24-bit weight planes (the product default is 16-bit,
-    return ds, model                  # covered by its own tests at its own bar)
+    return ds, model
 
 
 def match_boxes(boxes_a, scores_a, labels_a, boxes_b, scores_b, labels_b, iou_tol=1e-3, score_tol=1e-3, z_tol=1e-3):
