@@ -51,7 +51,7 @@ def rank_seed0(rank):
     return 4 + N_FRAMES * int(rank)
 
 
-def build(cfg_path, dev, n_points=N_POINTS, n_voxels=N_VOXELS, seed0=4, static=False, calibrate_hm=None):
+def build(cfg_path, dev, n_points=N_POINTS, n_voxels=N_VOXELS, seed0=4, static=False, calibrate_hm=None, batch=1):
     from amdq3d import quant
     from amdq3d.config import AttrDict, cfg_from_yaml_file
     from amdq3d.datasets import SyntheticDataset, load_data_to_gpu
@@ -76,7 +76,8 @@ def build(cfg_path, dev, n_points=N_POINTS, n_voxels=N_VOXELS, seed0=4, static=F
     # row capacities (printed in `config`): voxel level >= the frames' 30 000 / 20 000 voxels; every strided level 2.5 x that (the
     # largest strided level of the 64 frames that ranks 0-7 run holds 66 132 rows, tests/test_host_cpu.py). A frame that outgrows
     # a level raises — nothing is truncated silently.
-    model.voxel_capacity = int(os.environ.get("AQ3D_VOXEL_CAP", "40960"))
+    model.max_batch_size = int(batch)
+    model.voxel_capacity = int(os.environ.get("AQ3D_VOXEL_CAP", "40960")) * int(batch)
     model.level_capacity_factor = float(os.environ.get("AQ3D_LEVEL_FACTOR", "2.5"))
     if cfg.MODEL.NAME == "VoxelNeXt":
         quant.dynamic_quant_voxelnext(model, 8, 8, sq=True)
@@ -92,14 +93,15 @@ def build(cfg_path, dev, n_points=N_POINTS, n_voxels=N_VOXELS, seed0=4, static=F
     return cfg, ds, model, state
 
 
-def dense_launches(eng, kind):
-    """Kernel launches of the dense conv family per frame: a grouped step (<= 8 head branches) is ONE launch."""
+def dense_launches(eng, kind, B=1):
+    """Kernel launches of the dense conv family per step: a launch takes <= 8 (conv, sample) problems of one kernel class — a grouped
+    step (<= 8 head branches) is ONE launch at batch 1, the B images of a layer are one launch up to B = 8."""
     n = 0
     for k, arg in eng.steps:
         if k == "conv2d" and arg["kind"] == kind:
-            n += 1
+            n += (B + 7) // 8
         elif k == "conv2d_group" and arg["kind"] == kind:
-            n += 1
+            n += (B * len(arg["recs"]) + 7) // 8
     return n
 
 
@@ -107,6 +109,7 @@ def kernel_work(eng, cat):
     """Algorithmic work of ONE frame for a timed category: (bytes, ops, n_launches, bytes with SURVEY §8d's fp16 activations).
     `bytes` counts activations as they are stored here (fp32 between layers, int8 codes into the sparse convs); the second figure
     is §8d's convention (2-byte activations) for the same layers. Per-unit figures: DESIGN.md §3."""
+    B = int(getattr(eng, "bench_batch", 1))          # frames per step (bench.py --batch): B images per dense layer, B x the sparse rows
     if cat == "conv2d_i8":
         ops = byts = b16 = 0
         for r in eng.dense_convs:
@@ -114,10 +117,10 @@ def kernel_work(eng, cat):
                 continue
             g = r["geom"]
             L, K = g.Ho * g.Wo, g.Cin * g.ksize * g.ksize
-            ops += 2 * L * K * g.Cout
-            byts += g.H * g.W * g.Cin * 4 + L * g.Cout * 4 + K * g.Cout
-            b16 += g.H * g.W * g.Cin * 2 + L * g.Cout * 2 + K * g.Cout
-        return byts, ops, dense_launches(eng, "i8"), b16
+            ops += 2 * L * K * g.Cout * B
+            byts += (g.H * g.W * g.Cin * 4 + L * g.Cout * 4) * B + K * g.Cout
+            b16 += (g.H * g.W * g.Cin * 2 + L * g.Cout * 2) * B + K * g.Cout
+        return byts, ops, dense_launches(eng, "i8", B), b16
     if cat == "conv2d_f32":
         ops = byts = b16 = 0
         for r in eng.dense_convs:
@@ -126,10 +129,10 @@ def kernel_work(eng, cat):
             g = r["geom"]
             rows = g.Cout * (g.deconv * g.deconv if g.deconv else 1)
             L, K = g.Ho * g.Wo, g.Cin * g.ksize * g.ksize
-            ops += 2 * L * K * rows
-            byts += g.H * g.W * g.Cin * 4 + L * rows * 4 + K * rows * 4
-            b16 += g.H * g.W * g.Cin * 2 + L * rows * 2 + K * rows * 2
-        return byts, ops, dense_launches(eng, "f32"), b16
+            ops += 2 * L * K * rows * B
+            byts += (g.H * g.W * g.Cin * 4 + L * rows * 4) * B + K * rows * 4
+            b16 += (g.H * g.W * g.Cin * 2 + L * rows * 2) * B + K * rows * 2
+        return byts, ops, dense_launches(eng, "f32", B), b16
     if cat.startswith("spconv_c"):
         cout = int(cat[len("spconv_c"):])
         ops = byts = n = b16 = 0
@@ -162,19 +165,19 @@ def kernel_work(eng, cat):
     if cat == "voxelize":
         m = int(eng.levels[0]["count"].item())
         c = eng.num_point_features
-        return N_POINTS * c * 4 + m * (16 + 4 * c), 0, 1, None
+        return N_POINTS * B * c * 4 + m * (16 + 4 * c), 0, 1, None
     if cat == "scatter_dense" and not eng.fully_sparse:
         D, H, W = eng.bev_shape
         m = int(eng.levels[eng.encoded[1]]["count"].item())
         c = eng.encoded[0]["C"]
-        return D * H * W * c * 4 + m * c * 4, 0, 1, None
+        return D * H * W * c * 4 * B + m * c * 4, 0, 1, None
     if cat == "piece_absmax":
         byts = n = 0
         for r in eng.dense_convs:
             if r["kind"] == "i8" and r["pieces_owner"]:
                 g = r["geom"]
-                byts += g.H * g.W * g.Cin * 4
-                n += 1
+                byts += g.H * g.W * g.Cin * 4 * B
+                n += B
         return byts, 0, n, None
     if cat == "index_levels":
         byts = 0
@@ -447,6 +450,9 @@ def main():
                     "two int8 planes, layers within 1e-3 of their output scale, measured <= 1e-4) instead of the product default, 24-bit ones "
                     "(three planes, layers within 2e-5 of the oracle: the mode the test suite pins); the default run reports the other "
                     "mode beside `value`")
+    ap.add_argument("--batch", type=int, default=1, help="frames per step and launch (batch_size of tools/test.py): the kernels of a step "
+                    "work on B frames at once (B x the rows per sparse launch, B images per dense launch); dynamic quantiser statistics are "
+                    "then taken over the batch, as the reference's are. `value` stays frames/s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="timed frames of a SEPARATE CPU-baseline run; 0 (default): the int8 oracle "
@@ -469,7 +475,8 @@ def main():
     D.init("nccl")
     lib.load()
     cfg_path, n_points, n_voxels, wl_desc = WORKLOADS[args.workload]
-    cfg, ds, model, state = build(cfg_path, dev, n_points, n_voxels, seed0=rank_seed0(rank), static=args.static)
+    cfg, ds, model, state = build(cfg_path, dev, n_points, n_voxels, seed0=rank_seed0(rank), static=args.static, batch=args.batch)
+    B = max(1, int(args.batch))
     model.sparse_w16 = bool(args.sparse_w16)
     model.invalidate_engine()       # (the static recipe's calibration forwards have already compiled a plan)
 
@@ -477,7 +484,7 @@ def main():
     # H2D-inclusive figure)
     batches, host_pts = [], []
     for i in range(N_FRAMES):
-        b = ds.collate_batch([ds[i]])
+        b = ds.collate_batch([ds[(i + j) % N_FRAMES] for j in range(B)])      # step i works on frames i .. i + B - 1 (mod 8)
         host_pts.append(torch.from_numpy(np.ascontiguousarray(b["points"])).pin_memory())
         load_data_to_gpu(b, dev)
         batches.append(b)
@@ -487,6 +494,7 @@ def main():
             return model(dict(batches[i % len(batches)]))
 
     eng = model.engine()
+    eng.bench_batch = B
     # warm-up: first pass times every kernel family (eager launches, HIP events on the launch stream)
     eng.start_timing()
     n_warm = max(args.warmup, 1)
@@ -525,7 +533,7 @@ def main():
     torch.cuda.synchronize(dev)
     D.barrier()
     elapsed = time.perf_counter() - t0
-    total_frames, tmax, fps = D.aggregate_throughput(args.steps, elapsed, dev)
+    total_frames, tmax, fps = D.aggregate_throughput(args.steps * B, elapsed, dev)
     world_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
     # ---- everything below is outside the timed region
@@ -541,14 +549,14 @@ def main():
     # H2D-inclusive throughput: the 3 MB cloud comes from pinned host memory inside every step
     def from_host(i):
         p = host_pts[i % len(host_pts)].to(dev, non_blocking=True)
-        return {"points": p, "batch_size": 1, "frame_id": batches[i % len(batches)].get("frame_id")}
+        return {"points": p, "batch_size": B, "frame_id": batches[i % len(batches)].get("frame_id")}
     n_h2d = max(8, min(args.steps, 100))
     run_pipelined(2 * args.inflight, from_host)
     torch.cuda.synchronize(dev)
     a = time.perf_counter()
     run_pipelined(n_h2d, from_host)
     torch.cuda.synchronize(dev)
-    fps_h2d = n_h2d / (time.perf_counter() - a)
+    fps_h2d = n_h2d * B / (time.perf_counter() - a)
 
     # roofline leg: the same frames once more with HIP events around every launch of the dominant kernel family (events cannot
     # bracket single kernels inside a replayed graph, so this pass enqueues eagerly; same kernels, same inputs, same stream)
@@ -587,9 +595,9 @@ def main():
             "ms_per_step": tmax / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int8", "data": "synthetic",
             "config": {"workload": wl_desc.replace("w8a8 dynamic", "w8a8 static (calibrated amax)") if args.static else wl_desc,
-                       "frames_per_rank": N_FRAMES, "frame_seeds": "4 + 8*rank + i", "points": n_points,
+                       "frames_per_rank": N_FRAMES, "frame_seeds": "4 + 8*rank + i", "frames_per_step": B, "points": n_points,
                        "voxels": n_voxels, "parallelism": "replicas(frames)x%d" % world, "world_size_seen_by_rccl": world_seen,
-                       "avg_boxes_per_frame": n_det / max(args.steps, 1),
+                       "avg_boxes_per_frame": n_det / max(args.steps * B, 1),
                        "row_capacity_per_index_level": [lv["cap"] for lv in eng.levels],
                        "sparse_conv_weights": "16-bit fixed point, two int8 planes (layers <= 1e-3 of scale)" if args.sparse_w16
                        else "24-bit fixed point, three int8 planes (layers <= 2e-5 of scale)"},
@@ -606,6 +614,17 @@ def main():
                                     "what": "same pipeline, every frame's points copied from pinned host memory inside the step (rank 0)"},
             "warmup_breakdown_ms_per_frame": {k: v[1] / n_warm for k, v in sorted(warm.items(), key=lambda kv: -kv[1][1])},
         }
+        if B > 1:             # the oracle runs one sample at a time: a batch's dynamic statistics have no single-sample counterpart
+            out["accuracy"] = None
+            out["cpu_baseline"] = None
+            if not args.no_cpu_baseline:
+                try:
+                    out["cpu_baseline"] = cpu_baseline(cfg, ds, state, 2, 1, args.cpu_threads)
+                except Exception as e:
+                    out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+            print(json.dumps(out), flush=True)
+            D.shutdown()
+            return
         if args.static:       # the oracle legs below restate the dynamic recipe
             out["accuracy"] = out["cpu_baseline"] = None
             print(json.dumps(out), flush=True)

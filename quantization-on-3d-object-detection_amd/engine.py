@@ -452,9 +452,9 @@ class Engine:
                        out_boxes=torch.zeros((self.NSLOT, B, K, nb), dtype=f32, device=dev),
                        out_scores=torch.zeros((self.NSLOT, B, K), dtype=f32, device=dev),
                        out_labels=torch.zeros((self.NSLOT, B, K), dtype=torch.int64, device=dev),
-                       dec_ws=torch.empty((max(L.aq3d_voxel_decode_workspace_bytes(ctypes.byref(cfg), self.levels[oi]["cap"]), 256),),
+                       dec_ws=torch.empty((B, max(L.aq3d_voxel_decode_workspace_bytes(ctypes.byref(cfg), self.levels[oi]["cap"]), 256)),
                                           dtype=torch.uint8, device=dev),
-                       nms_ws=torch.empty((max(L.aq3d_nms_workspace_bytes(K), 256),), dtype=torch.uint8, device=dev))
+                       nms_ws=torch.empty((B, max(L.aq3d_nms_workspace_bytes(K), 256)), dtype=torch.uint8, device=dev))
             self.heads.append(rec)
         self.det_counts = torch.zeros((self.NSLOT, self.batch_cap, len(self.heads)), dtype=i32, device=dev)
         self.dense_convs = []
@@ -677,9 +677,10 @@ class Engine:
                        out_boxes=torch.zeros((self.NSLOT, B, K, nb), dtype=f32, device=dev),
                        out_scores=torch.zeros((self.NSLOT, B, K), dtype=f32, device=dev),
                        out_labels=torch.zeros((self.NSLOT, B, K), dtype=torch.int64, device=dev),
-                       dec_ws=torch.empty((max(L_.aq3d_center_decode_workspace_bytes(ctypes.byref(cfg)), 256),),
+                       # (one workspace per sample: the (sample, head) pairs of a batch share launches)
+                       dec_ws=torch.empty((B, (max(L_.aq3d_center_decode_workspace_bytes(ctypes.byref(cfg)), 256) + 255) // 256 * 256),
                                           dtype=torch.uint8, device=dev),
-                       nms_ws=torch.empty((max(L_.aq3d_nms_workspace_bytes(K), 256),), dtype=torch.uint8, device=dev))
+                       nms_ws=torch.empty((B, (max(L_.aq3d_nms_workspace_bytes(K), 256) + 255) // 256 * 256), dtype=torch.uint8, device=dev))
             self.heads.append(rec)
         self.det_counts = torch.zeros((self.NSLOT, B, len(self.heads)), dtype=i32, device=dev)
         self._group_head_convs(head_branch_first, B)
@@ -802,7 +803,7 @@ class Engine:
     def _run_conv2d_group(self, G, B):
         recs, kind = G["recs"], G["kind"]
         if G["conv_args"] is None:       # pointers are stable from here on: build the ctypes arrays once
-            G["conv_args"] = [ops.conv_problems(G["problems"](b)) for b in range(self.batch_cap)]
+            G["conv_args"] = {}
             if kind == "i8":
                 G["sq_args"] = ops.sq_prep_problems([dict(
                     pieces=self.arena.view(r["pieces"], (16, r["geom"].Cin)), weight=r["weight"], w_colmax=r["w_colmax"], g=r["geom"],
@@ -818,12 +819,22 @@ class Engine:
             with _Timed(self, "sq_prep"):
                 ops.sq_prep_group(G["sq_args"], recs[0]["w_bits"], recs[0]["a_bits"])
             with _Timed(self, "conv2d_i8"):
-                for b in range(B):
-                    ops.conv2d_i8_group(G["conv_args"][b])
+                for args in self._batched_problems(G["conv_args"], G["problems"], B):
+                    ops.conv2d_i8_group(args)
         else:
             with _Timed(self, "conv2d_f32"):
-                for b in range(B):
-                    ops.conv2d_f32_group(G["conv_args"][b])
+                for args in self._batched_problems(G["conv_args"], G["problems"], B):
+                    ops.conv2d_f32_group(args)
+
+    @staticmethod
+    def _batched_problems(cache, problems_of, B):
+        """The (conv, sample) problems of one plan step for a batch of B samples as ctypes arrays of <= 8 problems — one launch each
+        (a launch's problems share the kernel class; the samples of a batch are just more problems: B images per launch instead of B
+        launches). Built once per batch size."""
+        if B not in cache:
+            flat = [p for b in range(B) for p in problems_of(b)]
+            cache[B] = [ops.conv_problems(flat[i:i + 8]) for i in range(0, len(flat), 8)]
+        return cache[B]
 
     # ------------------------------------------------------------------ execution
     def _voxel_cfg(self, stride, has_b):
@@ -1049,18 +1060,30 @@ class Engine:
                                         rec["post_shift"], out=out[b], workspace=rec["sq16_ws"])
                 return
             with _Timed(self, "conv2d_i8"):
-                for b in range(B):
-                    ops.conv2d_i8(x[b], rec["params"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b],
+                if B > 1:
+                    for args in self._batched_problems(rec.setdefault("_batch_args", {}), lambda b: [dict(
+                            x=x[b], w=rec["params"], g=g, bias=rec["bias"], post_scale=rec["post_scale"], post_shift=rec["post_shift"],
+                            y=out[b], pieces_out=po, pieces_mode=rec["pieces_out"][2] if po is not None else 0)], B):
+                        ops.conv2d_i8_group(args)
+                else:
+                    ops.conv2d_i8(x[0], rec["params"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[0],
                                   pieces_out=po, pieces_mode=rec["pieces_out"][2] if po is not None else 0)
         else:
             cal = rec.get("calib")
             if cal is not None:
                 self._harvest_calib(rec, cal, B)
             with _Timed(self, "conv2d_f32"):
-                for b in range(B):
-                    ops.conv2d_f32(x[b], rec["weight"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b],
-                                   pieces_out=po, weight_split=rec.get("w_split"),
-                                   pieces_mode=rec["pieces_out"][2] if po is not None else 0)
+                if B > 1 and cal is None:
+                    for args in self._batched_problems(rec.setdefault("_batch_args", {}), lambda b: [dict(
+                            x=x[b], w=rec["weight"], g=g, bias=rec["bias"], post_scale=rec["post_scale"], post_shift=rec["post_shift"],
+                            y=out[b], pieces_out=po, pieces_mode=rec["pieces_out"][2] if po is not None else 0,
+                            w_split=rec.get("w_split"))], B):
+                        ops.conv2d_f32_group(args)
+                else:
+                    for b in range(B):
+                        ops.conv2d_f32(x[b], rec["weight"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[b],
+                                       pieces_out=po, weight_split=rec.get("w_split"),
+                                       pieces_mode=rec["pieces_out"][2] if po is not None else 0)
 
     def _harvest_calib(self, rec, cal, B):
         """Calibration forward of an SQConv2d/QuantConv2d: the amax its two quantizers would see this batch."""
@@ -1082,33 +1105,33 @@ class Engine:
         if wq_._if_calib:
             wq_.collect(amax_w)
 
-    def _head_batches(self, b, make):
-        """ctypes problem arrays of aq3d_decode_nms_batch for result slot self.slot and sample b: <= 8 heads per launch, built once."""
-        key = (self.slot, b)
+    def _head_batches(self, B, make):
+        """ctypes problem arrays of aq3d_decode_nms_batch for result slot self.slot and a batch of B samples: <= 8 (sample, head)
+        pairs per launch, built once."""
+        key = (self.slot, B)
         if key not in self._head_args:
-            recs = [make(hi, h) for hi, h in enumerate(self.heads)]
+            recs = [make(hi, h, b) for b in range(B) for hi, h in enumerate(self.heads)]
             self._head_args[key] = [(ops.head_problems(recs[i:i + 8]), recs[i:i + 8]) for i in range(0, len(recs), 8)]
         return self._head_args[key]
 
     def _head_common(self, hi, h, b):
         cap_nms = min(h["K"], h["pre"])
         return dict(cfg=h["cfg"], cand=(h["cand_boxes"][b], h["cand_scores"][b], h["cand_labels"][b], h["cand_count"][b]),
-                    dec_ws=h["dec_ws"], thresh=h["thresh"], nms_cap=cap_nms, post_max=h["post"], keep=h["keep"][b],
-                    keep_count=self.det_counts[self.slot, b, hi:hi + 1], nms_ws=h["nms_ws"], class_map=h["class_map"],
+                    dec_ws=h["dec_ws"][b], thresh=h["thresh"], nms_cap=cap_nms, post_max=h["post"], keep=h["keep"][b],
+                    keep_count=self.det_counts[self.slot, b, hi:hi + 1], nms_ws=h["nms_ws"][b], class_map=h["class_map"],
                     out=(h["out_boxes"][self.slot, b], h["out_scores"][self.slot, b], h["out_labels"][self.slot, b]))
 
     def _decode_nms(self, B):
         """center_head.py:297-365 for every head: top-K, decode, rotated NMS, gather — five launches for up to 8 heads."""
-        for b in range(B):
-            def make(hi, h):
-                s = h["slots"]
-                buf = h["buf"][b].view(-1, self.HEAD_LD)
-                r = self._head_common(hi, h, b)
-                r.update(hm=buf[:, s["hm"]:], center=buf[:, s["center"]:], center_z=buf[:, s["center_z"]:], dim=buf[:, s["dim"]:],
-                         rot=buf[:, s["rot"]:], vel=buf[:, s["vel"]:] if h["has_vel"] else None)
-                return r
-            for args, _ in self._head_batches(b, make):
-                ops.decode_nms_batch(args)
+        def make(hi, h, b):
+            s = h["slots"]
+            buf = h["buf"][b].view(-1, self.HEAD_LD)
+            r = self._head_common(hi, h, b)
+            r.update(hm=buf[:, s["hm"]:], center=buf[:, s["center"]:], center_z=buf[:, s["center_z"]:], dim=buf[:, s["dim"]:],
+                     rot=buf[:, s["rot"]:], vel=buf[:, s["vel"]:] if h["has_vel"] else None)
+            return r
+        for args, _ in self._head_batches(B, make):
+            ops.decode_nms_batch(args)
 
     def run_head_from(self, bev_nhwc):
         """Run only shared conv → head branches → decode → NMS on given BEV features [B, H, W, C] (parity tests feed
@@ -1149,7 +1172,7 @@ class Engine:
         if self._graph_now:
             batch_dict = self._stage_points(batch_dict)
             self._static_batch = batch_dict
-        self._phase(("all", self.slot), lambda: self._enqueue(batch_dict, B))
+        self._phase(("all", self.slot, B), lambda: self._enqueue(batch_dict, B))
         self._publish()
         return B
 
@@ -1199,7 +1222,9 @@ class Engine:
 
     # ------------------------------------------------------------------ hipGraph replay
     def _graph_ok(self, batch_dict, B):
-        if not self.use_graph or self.timers is not None or B != 1 or "points" not in batch_dict:
+        if not self.use_graph or self.timers is not None or "points" not in batch_dict:
+            return False
+        if B > 1 and self.fully_sparse:
             return False
         if self._calibrating is None:   # calibration forwards harvest statistics on the host between launches: eager only
             self._calibrating = any(r["quant"] is not None and r["quant"]["calib"] for r in self.sparse_convs) or \
@@ -1209,6 +1234,8 @@ class Engine:
         if "voxels" in batch_dict and not getattr(self.det, "voxelize_on_device", False):
             return False
         pts = batch_dict["points"]
+        if B > 1 and pts.shape[1] != self.num_point_features + 1:      # a batch needs the sample index column (collate_batch)
+            return False
         return pts.is_cuda and pts.dtype == f32 and pts.dim() == 2
 
     def _stage_points(self, batch_dict):
@@ -1232,7 +1259,7 @@ class Engine:
         if self._pts_n > n:
             buf[n:self._pts_n] = self._pts_far
         self._pts_n = n
-        return {"points": buf, "batch_size": 1}
+        return {"points": buf, "batch_size": int(batch_dict["batch_size"])}
 
     def _publish(self):
         """Detection counts of this frame → pinned host memory, stream-ordered, plus an event: collect() waits for THIS frame
@@ -1295,16 +1322,14 @@ class Engine:
         ops.level_merge_sum(levels, [x["buf"] for x, _, _ in m["srcs"]], scales, lv["index"], feats_out=m["out"]["buf"])
 
     def _voxel_decode_nms(self):
-        b = 0
-
-        def make(hi, h):
+        def make(hi, h, b):
             lv = self.levels[h["level"]]
             o = h["outs"]
             r = self._head_common(hi, h, b)
             r.update(hm=o["hm"]["buf"], center=o["center"]["buf"], center_z=o["center_z"]["buf"], dim=o["dim"]["buf"], rot=o["rot"]["buf"],
                      vel=o["vel"]["buf"] if h["has_vel"] else None, coords=lv["coords"], count=lv["count"])
             return r
-        for args, _ in self._head_batches(b, make):
+        for args, _ in self._head_batches(1, make):
             ops.decode_nms_batch(args)
 
     # ------------------------------------------------------------------ results

@@ -277,3 +277,45 @@ def test_voxelnext_frames_in_flight_on_four_plans_are_bit_identical(dev, w16):
             bad += 0 if _same(ref[k], _np(p.result()[0][0])) else 1
             n += 1
     assert len(model._extra_engines) == 3 and n == 40 and bad == 0, "%d of %d pipelined frames deviate" % (bad, n)
+
+
+@pytest.mark.parametrize("B", [2, 4])
+def test_batches_replay_as_graphs_and_share_launches(dev, B):
+    """bench.py --batch / tools/test.py --batch_size: a batch of B frames is ONE captured graph whose dense layers and decode / NMS take
+    the B samples as problems of the same launches. fp32 model: every sample's detections equal the single-frame ones bit for bit
+    (frames are independent); SmoothQuant w8a8 (statistics over the batch, as the reference's unfold over B * L rows): graph replay
+    and pipelined batches equal the eager batch bit for bit."""
+    from amdq3d import quant
+    from amdq3d.datasets import load_data_to_gpu
+    cfg = small_cfg("waymo")
+    ds, model = build_model(cfg, n_points=9000, n_voxels=2500, n_frames=4)
+    model.max_batch_size = B
+    model.cuda()
+    batch = ds.collate_batch([ds[i] for i in range(B)])
+    load_data_to_gpu(batch, dev)
+    with torch.no_grad():
+        singles = [_np(model(_batch(ds, i, dev))[0][0]) for i in range(B)]
+        for _ in range(3):                  # eager warm-up, capture, replay
+            got = [_np(p) for p in model(dict(batch))[0]]
+    assert any(k[2] == B for k in model.engine()._graphs), "the batch was not captured as a graph"
+    assert all(len(s[1]) > 0 for s in singles)
+    for s, g in zip(singles, got):
+        assert _same(s, g)
+    quant.quant(model, 8, 8, sq=True, alpha=0.5, static=False)
+    model.cuda()
+    eng = model.engine()
+    eng.use_graph = False
+    with torch.no_grad():
+        ref = [_np(p) for p in model(dict(batch))[0]]
+    eng.use_graph = True
+    with torch.no_grad():
+        for _ in range(3):
+            got = [_np(p) for p in model(dict(batch))[0]]
+        pend = [model.forward_async(dict(batch)) for _ in range(4)]
+        outs = [[_np(p) for p in f.result()[0]] for f in pend]
+    assert any(k[2] == B for k in eng._graphs)
+    for r, g in zip(ref, got):
+        assert _same(r, g)
+    for o in outs:
+        for r, g in zip(ref, o):
+            assert _same(r, g)
