@@ -453,6 +453,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="frames per step and launch (batch_size of tools/test.py): the kernels of a step "
                     "work on B frames at once (B x the rows per sparse launch, B images per dense launch); dynamic quantiser statistics are "
                     "then taken over the batch, as the reference's are. `value` stays frames/s")
+    ap.add_argument("--replay-only", action="store_true", help="profiling aid: one eager frame to settle the plans, then ONLY graph-replayed "
+                    "frames (no event-timed passes, no latency / H2D / roofline / oracle legs): a rocprofv3 kernel trace of this run counts "
+                    "what a replayed frame launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accuracy", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="timed frames of a SEPARATE CPU-baseline run; 0 (default): the int8 oracle "
@@ -496,12 +499,16 @@ def main():
     eng = model.engine()
     eng.bench_batch = B
     # warm-up: first pass times every kernel family (eager launches, HIP events on the launch stream)
-    eng.start_timing()
     n_warm = max(args.warmup, 1)
-    for i in range(n_warm):
-        step(i)
-    warm = eng.stop_timing()
-    dominant = max(warm.items(), key=lambda kv: kv[1][1])[0] if warm else None
+    if args.replay_only:
+        step(0)
+        warm, dominant = {}, None
+    else:
+        eng.start_timing()
+        for i in range(n_warm):
+            step(i)
+        warm = eng.stop_timing()
+        dominant = max(warm.items(), key=lambda kv: kv[1][1])[0] if warm else None
 
     if args.inflight <= 0:
         args.inflight = max(1, int(model.async_streams))
@@ -536,6 +543,13 @@ def main():
     total_frames, tmax, fps = D.aggregate_throughput(args.steps * B, elapsed, dev)
     world_seen = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
 
+    if args.replay_only:
+        if rank == 0:
+            print(json.dumps({"metric": "frames/s (replay-only profiling run)", "value": fps, "unit": "frames/s", "n_gpus": world,
+                              "steps": args.steps, "frames_per_step": B, "ms_per_step": tmax / max(args.steps, 1) * 1e3,
+                              "graph_warmup_steps": 4 * eng.NSLOT * max(1, args.inflight)}), flush=True)
+        D.shutdown()
+        return
     # ---- everything below is outside the timed region
     intervals_ms = [1e3 * (b - a) for a, b in zip(stamps[:-1], stamps[1:])][args.inflight:]      # steady state: completion to completion
     # single-frame latency: one frame in flight, enqueue → counts on the host

@@ -148,6 +148,9 @@ __device__ __forceinline__ int ix_block_scan(int v, int *lds4, int *total) {
 // no second launch). Hand-off form of MI355X_MICROARCH.md "Valid forms", row 1: write-through (agent-scope) stores by the
 // signalling wave, its s_waitcnt vmcnt(0), an agent-scope ticket add by one lane; the workgroup whose add returns last reads
 // with agent-scope loads behind its own barrier. Returns true in the last workgroup only.
+// CONTRACT: every store that the last workgroup's scan reads must be issued by WAVE 0 of the signalling workgroup, before
+// this call — the s_waitcnt below drains wave 0's stores only. ix_count stores with threads 0 .. IX_CPB-1 (static_assert there),
+// ix_dilate with thread 0. A store moved to another wave needs a __syncthreads() + release fence in front of the ticket instead.
 #define IX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 __device__ __forceinline__ bool ix_arrive(int *ticket, int nblocks, int *lds_flag) {
     if (threadIdx.x == 0) {
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_mark_coords(const int *__restrict
 // 8- or 16-byte loads all give 21-24 us for that level — the pass is bound by reading the 11.6 MB bitmap the memset and the
 // points' atomics have just written, not by the tickets.
 #define IX_CPB 8
+static_assert(IX_CPB <= 64, "ix_count's chunk sums are stored by threads 0 .. IX_CPB-1, which must all be in wave 0 (ix_arrive's contract)");
 __global__ __launch_bounds__(IX_BLOCK) void ix_count(Lv L, IxWs ws, int nchunks) {
     __shared__ int lds4[IX_BLOCK / 64];
     __shared__ int part[IX_CPB][2];

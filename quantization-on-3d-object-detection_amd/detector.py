@@ -10,11 +10,13 @@ built extension the forward raises.
 """
 import os
 
+import numpy as np
+
 import torch
 import torch.nn as nn
 
 from . import modules as M
-from .engine import Engine
+from .engine import Engine, LevelOverflow
 from .quant import surgery_epoch
 
 VFE = {"MeanVFE": M.MeanVFE}
@@ -44,9 +46,14 @@ class Detector3DTemplate(nn.Module):
         self.max_batch_size = 1          # engine buffers are sized for this many frames per forward
         self.voxel_capacity = None       # rows of the voxel level (default MAX_NUMBER_OF_VOXELS * max_batch_size)
         # rows of every derived (strided / merged) index level: factor x voxel_capacity, never more than the level has cells, or the
-        # explicit {level index: rows}. A frame that outgrows a level RAISES ValueError (spconv would allocate more rows).
+        # explicit {level index: rows}. A frame that outgrows a level is handled like one that exceeds MAX_NUMBER_OF_VOXELS: the level's
+        # buffers grow (1.25 x what the frame needs), the plans are rebuilt and the frame is run again, once per level at most — spconv
+        # sizes its outputs dynamically (spconv_backbone.py:230-231), so a dense real frame must not become an exception.
+        # level_capacity_grow = False: raise ValueError (engine.LevelOverflow) instead, e.g. to keep memory bounded in a serving loop.
         self.level_capacity_factor = 4.0
         self.level_capacity = None
+        self.level_capacity_grow = True
+        self.level_regrows = 0           # frames that had to be run again after growing a level
         self.voxelize_on_device = True   # False: consume batch_dict['voxels'/'voxel_coords'] when present
         # quantised sparse convs (int8 codes x fixed-point weight planes on the int8 matrix pipe): False (default) = 24-bit weights
         # (three int8 planes, fp32-grade sums, every layer within 2e-5 of the oracle); True = 16-bit weights (two planes: <= 2^-9 per
@@ -264,6 +271,7 @@ class PendingFrame:
         self.det, self.eng, self.slot, self.B, self.batch_dict = det, eng, slot, B, batch_dict
         self.generation = eng.slot_generation[slot]      # the plan's result slot is reused NSLOT frames later
         self._counts = None
+        self._redo = None               # (pred_dicts, recall_dict) of a frame that was run again after a level had to grow
 
     def _check_live(self):
         if self.eng.slot_generation[self.slot] != self.generation:
@@ -273,14 +281,30 @@ class PendingFrame:
     def counts(self):
         """Detections per (sample, head) — one event wait + a pinned-host read, no tensor slicing."""
         if self._counts is None:
-            self._check_live()
-            self._counts = self.eng.counts(self.B, self.slot)
+            if self._redo is None:
+                self._check_live()
+                try:
+                    self._counts = self.eng.counts(self.B, self.slot)
+                except LevelOverflow as err:
+                    self._redo = self.det._grow_and_rerun(err, self.batch_dict)
+            if self._redo is not None:
+                nh = len(self.eng.heads)
+                c = np.zeros((self.B, nh), dtype=np.int32)
+                for b, p in enumerate(self._redo[0]):
+                    c[b, 0] = len(p["pred_scores"])          # (per-head split is not kept for a re-run frame)
+                self._counts = c
         return self._counts
 
     def result(self):
         """→ (pred_dicts, recall_dict), exactly what Detector.forward returns."""
+        if self._redo is not None:
+            return self._redo
         self._check_live()
-        self.batch_dict["final_box_dicts"] = self.eng.collect(self.B, self.slot)
+        try:
+            self.batch_dict["final_box_dicts"] = self.eng.collect(self.B, self.slot)
+        except LevelOverflow as err:
+            self._redo = self.det._grow_and_rerun(err, self.batch_dict)
+            return self._redo
         return self.det.post_processing(self.batch_dict)
 
 
@@ -301,7 +325,34 @@ class CenterPoint(Detector3DTemplate):
             if getattr(e, "stream", None) is not None:
                 cur.wait_stream(e.stream)
         eng.run(batch_dict)
-        batch_dict["final_box_dicts"] = eng.collect(B)
+        try:
+            batch_dict["final_box_dicts"] = eng.collect(B)
+        except LevelOverflow as err:
+            return self._grow_and_rerun(err, batch_dict)
+        return self.post_processing(batch_dict)
+
+    def _grow_and_rerun(self, err, batch_dict, depth=0):
+        """A level outgrew its buffers: give it 1.25 x the rows the frame needs, rebuild the plans (frames still in flight keep their
+        old plans alive through their PendingFrame handles) and run the frame again, synchronously."""
+        if not self.level_capacity_grow or depth > 16:
+            raise err
+        rows = (int(err.total * 1.25) + 255) // 256 * 256
+        if err.level == 0:
+            self.voxel_capacity = rows
+        else:
+            caps = dict(self.level_capacity or {})
+            caps[err.level] = rows
+            self.level_capacity = caps
+        torch.cuda.synchronize(self._device())
+        self.invalidate_engine()
+        self.level_regrows += 1
+        eng = self.engine()
+        B = int(batch_dict["batch_size"])
+        eng.run(batch_dict)
+        try:
+            batch_dict["final_box_dicts"] = eng.collect(B)
+        except LevelOverflow as err2:
+            return self._grow_and_rerun(err2, batch_dict, depth + 1)
         return self.post_processing(batch_dict)
 
     def forward_async(self, batch_dict):

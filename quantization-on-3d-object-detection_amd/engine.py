@@ -111,6 +111,14 @@ class _Timed:
             self.eng.timers.setdefault(self.cat, []).append((self.e0, self.e1))
 
 
+class LevelOverflow(ValueError):
+    """An index level of a frame has more active sites than its buffers have rows (the frame was not computed)."""
+
+    def __init__(self, level, total, cap, msg):
+        super().__init__(msg)
+        self.level, self.total, self.cap = int(level), int(total), int(cap)
+
+
 class Engine:
     NSLOT = 2     # result slots: frame N+1 can be enqueued while frame N's detections are still being read back
 
@@ -1354,9 +1362,10 @@ class Engine:
             total = int(st[li, 1])
             if total > lv["cap"]:
                 what = "voxel_capacity" if li == 0 else "level_capacity[%d] / level_capacity_factor" % li
-                raise ValueError("index level %d: %d active sites > capacity %d rows — the frame was NOT computed; raise "
-                                 "detector.%s (spconv sizes its outputs dynamically, spconv_backbone.py:230-231)"
-                                 % (li, total, lv["cap"], what))
+                raise LevelOverflow(li, total, lv["cap"],
+                                    "index level %d: %d active sites > capacity %d rows — the frame was NOT computed; raise "
+                                    "detector.%s (spconv sizes its outputs dynamically, spconv_backbone.py:230-231)"
+                                    % (li, total, lv["cap"], what))
 
     def _rerun_first_seen(self, slot, batch_dict, B):
         """Rare path: a sample holds more than MAX_NUMBER_OF_VOXELS voxels. Everything in flight on the device finishes, then the

@@ -183,15 +183,29 @@ def test_stale_pending_frame_raises_and_weight_load_rebuilds_the_plan(dev, monke
     assert len(got[1]) < len(ref[1])
 
 
-def test_capacity_overflow_raises(dev):
+def test_capacity_overflow_grows_the_level_or_raises(dev):
     """A strided level that outgrows its buffers (spconv would simply allocate more, spconv_backbone.py:230-231) must not be
-    computed on a truncated site set: counts() / forward() raise and name the level; with room the same frame runs."""
+    computed on a truncated site set. Default: the level's buffers grow, the plans are rebuilt and the frame is run again — same
+    detections as with room from the start (forward, forward_async, several levels at once). level_capacity_grow = False: counts() /
+    forward() raise and name the level."""
     ds, model = _model(quantized=False)
     with torch.no_grad():
         ref = _np(model(_batch(ds, 0, dev))[0][0])
     eng = model.engine()
     live = [int(lv["count"].item()) for lv in eng.levels]
     assert all(n > 0 for n in live)
+    model.level_capacity = {1: max(256, live[1] // 2 // 256 * 256), 2: max(256, live[2] // 2 // 256 * 256)}
+    model.invalidate_engine()
+    with torch.no_grad():
+        got = _np(model(_batch(ds, 0, dev))[0][0])
+    assert _same(ref, got) and model.level_regrows == 2 and model.level_capacity[1] >= live[1] and model.level_capacity[2] >= live[2]
+    model.level_capacity = {3: max(256, live[3] // 2 // 256 * 256)}
+    model.invalidate_engine()
+    with torch.no_grad():
+        p = model.forward_async(_batch(ds, 0, dev))
+        assert int(p.counts().sum()) == len(ref[1])
+        assert _same(ref, _np(p.result()[0][0])) and model.level_regrows == 3
+    model.level_capacity_grow = False
     for use_graph in (False, True):
         model.level_capacity = {1: max(256, live[1] // 2 // 256 * 256)}
         model.invalidate_engine()
