@@ -336,9 +336,6 @@ typedef struct aq3d_conv2d_problem {
     float *pieces_out;
     int32_t pieces_ld, pieces_mode;
     const void *weight_split;          /* f32, optional: aq3d_conv2d_split_weight of the same weights (used by 1x1 / deconv GEMMs) */
-    int32_t kernel;                    /* i8 (read from problem 0 of a group): 0 = the library's choice; 1 = the per-step staging kernel of
-                                        * rounds 1-3 (the only form for ksize != 3); 2 / 3 = the tap-plane kernel with its small / large pixel
-                                        * tile. All forms produce identical bits. f32: ignored */
 } aq3d_conv2d_problem;
 
 /* Up to 8 independent convolutions of one launch class (same H, W, Cin, ksize, stride, pad; Cout on the same side of 128

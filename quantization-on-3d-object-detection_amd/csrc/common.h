@@ -31,6 +31,20 @@ static inline int aq3d_is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; 
 
 // Grid for a grid-stride loop over `work` items with `block` threads: enough blocks to fill
 // 256 CUs x 8 blocks, never more than the work needs.
+// Zero fill as an ordinary kernel of the caller's stream (16-byte stores, grid-stride): a hipMemsetAsync becomes a MEMSET NODE of a
+// captured hipGraph, which this runtime does not run like the kernel nodes around it (scratch/ablate.py, round 4).
+__global__ __launch_bounds__(256) static void aq3d_zero_kernel(uint4 *__restrict__ p, size_t n16, int tail) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && (int)threadIdx.x < tail) reinterpret_cast<unsigned char *>(p + n16)[threadIdx.x] = 0;
+}
+// p 16-byte aligned (device allocations are); any byte count
+static inline void aq3d_zero_async(void *p, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return;
+    const size_t n16 = bytes / 16;
+    const size_t blocks = n16 ? (n16 + 255) / 256 : 1;
+    hipLaunchKernelGGL(aq3d_zero_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, (uint4 *)p, n16, (int)(bytes % 16));
+}
+
 static inline int aq3d_grid(int64_t work, int block, int max_blocks = 2048) {
     int64_t g = (work + block - 1) / block;
     if (g < 1) g = 1;

@@ -395,243 +395,6 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
 #endif
 }
 
-// ------------------------------------------------------------------ int8 SmoothQuant conv, round 4: halo tile + tap planes in LDS
-// conv2d_i8_kernel above runs a K step (one tap x 64 channels) as one dependency chain per workgroup: global loads -> quantise ->
-// LDS -> barrier -> 4..16 MFMAs, 18..72 times. PMC (profiles/r03): 8.5 M VALU against 0.37 M MFMA instructions per dispatch, of
-// which only ~3.5 M are the quantisation the recipe prescribes (5.75 ops per element and tap: exact quotient, scale, round, pack);
-// the rest is per-step address / mask / staging work, every tap re-loads the fp32 pixels from L1 / L2, and every step ends at a
-// barrier with 64 cycles of matrix work behind it: 33 us for 128 -> 128 at 188 x 188, 6 % of the int8 roof.
-// Here (3 x 3, stride 1, pad 1) the kinds of work are separated inside the workgroup. Per 64-channel chunk:
-//   H  the chunk's fp32 halo tile ((PH + 2) x 10 pixels x 64 channels) goes from registers to LDS; the loads were issued a chunk
-//      earlier (every input element is fetched ONCE per tile; a pixel outside the image is an out-of-range offset = zeros = code 0,
-//      so nothing below knows about padding);
-//   Q  every thread owns one channel quad (its 9 x (s, 1/s) live in registers for the whole chunk) and a few output pixels; it reads
-//      the 9 tap windows of its pixels from the halo tile, quantises them and writes the codes into NINE tap planes
-//      [tap][pixel][64 B] in LDS: no global loads, no masks, no per-step bookkeeping;
-//   M  the planes are the B operands of 9 x TI x TJ MFMAs per wave; the weight fragments (A operands) come straight from global
-//      memory / L2 into registers, one tap ahead (a layer's int8 weights are 74 .. 590 KB, shared by all workgroups).
-// Three barriers per chunk instead of one per tap; a SIMD holds two waves, so one's Q (vector ALU) runs under the other's M (matrix
-// pipe). The codes, and therefore the int32 sums and every output bit, are those of the kernel above.
-// Tile: 64 * WM output channels x (PH x 8) pixels, PH = 2 * TJ * WN; wave (wm, wn) = 64 channels x 16 * TJ pixels.
-template <int WM, int WN, int TJ, int DBG = 0>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv2d_i8q_kernel(ConvGroup grp) {
-    constexpr int NTH = 64 * WM * WN, TI = 4, BM = 64 * WM, BN = 16 * TJ * WN, PH = BN / 8;
-    constexpr int PGS = NTH / 16, PPT = BN / PGS;
-    static_assert(BN % PGS == 0 && PPT >= 1, "pixels per staging thread");
-    constexpr int HW = 10, HALO = (PH + 2) * HW;                      // halo tile: (PH + 2) rows x 10 columns of input pixels
-    constexpr int NHL = (HALO + PGS - 1) / PGS;                       // halo pixels per thread (its channel quad of each)
-    constexpr int LD = 64;
-    const ConvArgs a = grp.p[blockIdx.z];
-    const int oc0 = blockIdx.y * BM;
-    if (oc0 >= a.Cout) return;
-    const int tiles_x = (a.Wo + 7) >> 3, ntiles = tiles_x * ((a.Ho + PH - 1) / PH);
-    // XCD-aware tile order (see conv2d_i8_kernel): gridDim.x is a multiple of 8, XCD x takes a contiguous range of tiles
-    const int bx = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);
-    if (bx >= ntiles) return;
-    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
-
-    constexpr int PLANES = 9 * BN * LD;
-    constexpr int PM_BYTES = 16 * BM * 4;
-    __shared__ __attribute__((aligned(16))) char smem[PLANES > PM_BYTES ? PLANES : PM_BYTES];
-    __shared__ __attribute__((aligned(16))) float xh[HALO * 64];      // fp32 halo tile of the chunk: [halo pixel][64 channels]
-    __shared__ __attribute__((aligned(16))) float ep[4][BM];
-    unsigned int *pm = reinterpret_cast<unsigned int *>(smem);       // piece maxima: the planes' memory, after the last chunk
-    auto swz = [](int row, int chunk) { return chunk ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3); };
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wn = wave / WM;
-    const int g = lane >> 4, l15 = lane & 15;
-    const int K = a.Cin * 9;
-    for (int i = tid; i < BM; i += NTH) {
-        const int oc = oc0 + i;
-        const bool in = oc < a.Cout;
-        ep[0][i] = in ? a.out_mul[oc] : 0.f;
-        ep[1][i] = (in && a.bias) ? a.bias[oc] : 0.f;
-        ep[2][i] = (in && a.post_scale) ? a.post_scale[oc] : 1.f;
-        ep[3][i] = (in && a.post_scale) ? a.post_shift[oc] : 0.f;
-    }
-    const float sx = a.scal[0];
-    const bool clamp = a.scal[3] != 0.f;
-
-    // staging role: thread = (channel quad cq of the chunk, pixel group pg)
-    const int cq = tid & 15, pg = tid >> 4;
-    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.H * a.W * a.in_ld * 4, 0x00020000);
-    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.Cout * K, 0x00020000);
-    const auto rsrc_s = __builtin_amdgcn_make_buffer_rsrc((void *)a.s, 0, K * 4, 0x00020000);
-    const auto rsrc_r = __builtin_amdgcn_make_buffer_rsrc((void *)a.rinv, 0, K * 4, 0x00020000);
-    unsigned hoff[NHL];                 // byte offset (chunk 0) of this thread's halo elements; out of range = not in the image
-#pragma unroll
-    for (int k = 0; k < NHL; ++k) {
-        const int hp = pg + PGS * k;
-        const int iy = ty * PH + hp / HW - 1, ix = tx * 8 + hp % HW - 1;
-        const bool ok = hp < HALO && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        hoff[k] = ok ? (unsigned)((iy * a.W + ix) * a.in_ld + cq * 4) * 4u : 0xfffffff0u;
-    }
-    int wrow[TI];                       // byte offset of this lane's weight row (A operand: lane (l15 = row, g = 16-byte K chunk))
-#pragma unroll
-    for (int i = 0; i < TI; ++i) wrow[i] = min(oc0 + wm * 64 + i * 16 + l15, a.Cout - 1) * K + g * 16;
-
-    i32x4 acc[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = (i32x4){0, 0, 0, 0};
-
-    f32x4 hreg[NHL];                    // the next chunk's halo elements, in flight
-    auto load_halo = [&](int c0) {
-#pragma unroll
-        for (int k = 0; k < NHL; ++k) {
-            const unsigned off = hoff[k] == 0xfffffff0u ? 0xfffffff0u : hoff[k] + (unsigned)c0 * 4u;
-            hreg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0));
-        }
-    };
-    load_halo(0);
-    auto chunk = [&](auto clamp_c, int c0) {
-        constexpr bool CL = decltype(clamp_c)::value;
-        // ---- H: halo tile of this chunk -> LDS; the next chunk's loads go out right away
-#pragma unroll
-        for (int k = 0; k < NHL; ++k) {
-            const int hp = pg + PGS * k;
-            if (HALO % PGS == 0 || hp < HALO) *reinterpret_cast<f32x4 *>(xh + hp * 64 + cq * 4) = hreg[k];
-        }
-        f32x4 sr[9], rr[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const unsigned col = (unsigned)(t * a.Cin + c0 + cq * 4) * 4u;
-            sr[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, col, 0, 0));
-            rr[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, col, 0, 0));
-        }
-        __syncthreads();
-        if (c0 + 64 < a.Cin) load_halo(c0 + 64);
-        // ---- Q: the chunk's nine tap planes
-        if (DBG != 1)
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const int lp = pg + PGS * i;
-            const float *src = xh + ((lp >> 3) * HW + (lp & 7)) * 64 + cq * 4;       // tap (0, 0) of output pixel lp
-            char *dst = smem + lp * LD + swz(lp, cq >> 2) * 16 + (cq & 3) * 4;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const f32x4 xv = *reinterpret_cast<const f32x4 *>(src + ((t / 3) * HW + (t % 3)) * 64);
-                *reinterpret_cast<int *>(dst + t * (BN * LD)) = quant_pack4<CL>(xv, sr[t], rr[t], sx);
-            }
-        }
-        // weight fragments of row tile 0, all nine taps: L2 latency (~600+ cycles) against 16 .. 64 cycles of matrix work per fragment —
-        // a one-tap prefetch left the whole M phase waiting (measured: M alone 30 us per layer). Nine loads per batch, the next
-        // row tile's batch in flight under this one's 9 x TJ MFMAs.
-        i32x4 af[2][9];
-        auto load_w = [&](i32x4 (&f)[9], int i) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-                f[t] = DBG == 3 ? (i32x4){wrow[i], t, c0, 1} : __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(wrow[i] + t * a.Cin + c0), 0, 0));
-        };
-        load_w(af[0], 0);
-        __syncthreads();
-        // ---- M: TI row tiles x 9 taps x TJ MFMAs per wave
-        if (DBG != 2)
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            if (i + 1 < TI) load_w(af[(i + 1) & 1], i + 1);
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) {
-                    const i32x4 bf = *reinterpret_cast<const i32x4 *>(smem + t * (BN * LD) + (wn * 16 * TJ + j * 16 + l15) * LD + swz(l15, g) * 16);
-                    acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i & 1][t], bf, acc[i][j], 0, 0, 0);
-                }
-            }
-        }
-        __syncthreads();                // planes and halo tile are free for the next chunk (or for the piece maxima)
-    };
-    if (clamp) {
-        for (int c0 = 0; c0 < a.Cin; c0 += 64) chunk(std::true_type{}, c0);
-    } else {
-        for (int c0 = 0; c0 < a.Cin; c0 += 64) chunk(std::false_type{}, c0);
-    }
-
-    // ---- epilogue (the one of conv2d_i8_kernel; lane holds channels base + 4g .. 4g+3 of pixel column l15)
-    if (a.pieces_out) {
-        for (int i = tid; i < 16 * BM; i += NTH) pm[i] = 0u;
-        __syncthreads();
-    }
-    int pix[TJ], pcls[TJ];              // global pixel index (-1: outside the image), piece class (-1 = interior in merged mode)
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-        const int lp = wn * 16 * TJ + j * 16 + l15;
-        const int ho = ty * PH + (lp >> 3), wo = tx * 8 + (lp & 7);
-        pix[j] = (ho < a.Ho && wo < a.Wo) ? ho * a.Wo + wo : -1;
-        pcls[j] = 0;
-        if (a.pieces_out)
-            pcls[j] = (a.pieces_mode == 1 && ho > 0 && ho < a.Ho - 1 && wo > 0 && wo < a.Wo - 1)
-                          ? -1 : piece_cls(ho, a.Ho) * 4 + piece_cls(wo, a.Wo);
-    }
-    f32x4 vout[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int ol = wm * 64 + i * 16 + 4 * g;
-        const int oc = oc0 + ol;
-        const f32x4 mul = *reinterpret_cast<const f32x4 *>(&ep[0][ol]), b = *reinterpret_cast<const f32x4 *>(&ep[1][ol]);
-        const f32x4 ps = *reinterpret_cast<const f32x4 *>(&ep[2][ol]), pt = *reinterpret_cast<const f32x4 *>(&ep[3][ol]);
-        float mint[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = __fmul_rn((float)acc[i][j][r], mul[r]);
-                if (a.bias) t = __fadd_rn(t, b[r]);
-                if (a.post_scale) t = __fadd_rn(__fmul_rn(t, ps[r]), pt[r]);
-                if (a.relu) t = fmaxf(t, 0.f);
-                v[r] = t;
-            }
-            vout[i][j] = v;
-            if (a.pieces_out && pix[j] >= 0 && oc < a.Cout) {
-                if (pcls[j] < 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mint[r] = fmaxf(mint[r], fabsf(v[r]));
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicMax(&pm[pcls[j] * BM + ol + r], __float_as_uint(fabsf(v[r])));
-                }
-            }
-        }
-        if (a.pieces_out && a.pieces_mode == 1) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float m = mint[r];
-                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x111, 0xf, 0xf, true)));
-                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x112, 0xf, 0xf, true)));
-                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x114, 0xf, 0xf, true)));
-                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x118, 0xf, 0xf, true)));
-                if (l15 == 15 && m > 0.f) atomicMax(&pm[10 * BM + ol + r], __float_as_uint(m));
-            }
-        }
-    }
-    if (a.pieces_out) {
-        __syncthreads();
-        for (int i = tid; i < 16 * BM; i += NTH) {
-            const unsigned int v = pm[i];
-            const int pc = i / BM, oc = oc0 + i % BM;
-            if (v != 0u && oc < a.Cout) {
-                unsigned int *dst = reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc * a.pieces_ld + a.out_coff + oc;
-                if (a.pieces_mode == 1) {       // merged interior maximum: spread over the four interior classes (see conv2d_i8_kernel)
-                    const int alt[4] = {10, 11, 14, 15};
-                    const int pc2 = pc == 10 ? alt[blockIdx.x & 3] : pc;
-                    atomicMax(reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc2 * a.pieces_ld + a.out_coff + oc, v);
-                } else if (v > *dst) atomicMax(dst, v);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int oc = oc0 + wm * 64 + i * 16 + 4 * g;
-        if (oc >= a.Cout) continue;
-#pragma unroll
-        for (int j = 0; j < TJ; ++j)
-            if (pix[j] >= 0) *reinterpret_cast<f32x4 *>(a.y + (size_t)pix[j] * a.out_ld + a.out_coff + oc) = vout[i][j];
-    }
-}
-
 // ------------------------------------------------------------------ fp32 conv / transposed conv
 // WM x WN waves; wave tile (TI*16) rows x (TJ*16) pixels; K step = KS input channels of one tap (KS = 32 halves the
 // barriers but measured no faster than 16, which is what is launched).
@@ -873,25 +636,6 @@ extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n,
     for (int i = n; i < AQ3D_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     const aq3d_conv2d_geom *g = probs[0].geom;
     const int L = g->Ho * g->Wo;
-    const int variant = probs[0].kernel;
-    AQ3D_REQUIRE(variant >= 0 && variant <= 3, "aq3d_conv2d_i8_group: kernel=%d not in 0..3", variant);
-    if (variant != 1 && g->ksize == 3 && g->pad == 1 && g->stride == 1) {
-        // round 4: halo tile + tap planes in LDS (conv2d_i8q_kernel). Tile = 64 * WM channels x BN pixels; of the two pixel-tile sizes
-        // the larger one when it still yields >= 2 workgroups per CU
-        const int wm = max_cout > 128 ? 4 : (max_cout > 64 ? 2 : 1);
-        const int ocb = aq3d_div_up(max_cout, 64 * wm);
-        auto tiles = [&](int bn) { return aq3d_div_up(g->Wo, 8) * aq3d_div_up(g->Ho, bn / 8); };
-        const bool large = (variant == 3 && wm != 2) || (variant == 0 && tiles(128) * ocb * n >= 512);
-        const int nt = tiles(large ? 128 : 64);
-        const dim3 grid(aq3d_div_up(nt, 8) * 8, ocb, n);
-#define AQ3D_I8Q_LAUNCH(WM_, WN_, TJ_) hipLaunchKernelGGL((conv2d_i8q_kernel<WM_, WN_, TJ_>), grid, dim3(64 * WM_ * WN_), 0, stream, grp)
-        if (wm == 4) { if (large) AQ3D_I8Q_LAUNCH(4, 2, 4); else AQ3D_I8Q_LAUNCH(4, 2, 2); }
-        else if (wm == 2) { if (variant == 3 && g->relu == 0) hipLaunchKernelGGL((conv2d_i8q_kernel<2, 2, 2, 3>), grid, dim3(256), 0, stream, grp); else if (variant == 3) hipLaunchKernelGGL((conv2d_i8q_kernel<2, 2, 2, 1>), grid, dim3(256), 0, stream, grp); else if (g->relu == 0) hipLaunchKernelGGL((conv2d_i8q_kernel<2, 2, 2, 2>), grid, dim3(256), 0, stream, grp); else AQ3D_I8Q_LAUNCH(2, 2, 2); }
-        else { if (large) AQ3D_I8Q_LAUNCH(1, 4, 2); else AQ3D_I8Q_LAUNCH(1, 4, 1); }
-#undef AQ3D_I8Q_LAUNCH
-        AQ3D_CHECK_LAUNCH("aq3d_conv2d_i8(q)");
-        return AQ3D_OK;
-    }
     // pixel-tile width: enough workgroups for >= 2 per CU (the K loop is a latency chain, it needs co-resident partners)
     const int ocb = max_cout >= 128 ? aq3d_div_up(max_cout, 128) : aq3d_div_up(max_cout, 64);
     int bn = 128;
@@ -928,7 +672,6 @@ extern "C" int aq3d_conv2d_i8(const float *x, const void *params, const aq3d_con
     AQ3D_REQUIRE(g, "aq3d_conv2d_i8: null argument");
     aq3d_conv2d_problem q;
     q.weight_split = nullptr;
-    q.kernel = 0;
     q.x = x; q.weight_or_params = params; q.geom = g; q.bias = bias; q.post_scale = post_scale; q.post_shift = post_shift;
     q.y = y; q.pieces_out = pieces_out; q.pieces_ld = pieces_ld; q.pieces_mode = pieces_mode;
     return aq3d_conv2d_i8_group(&q, 1, stream_);
@@ -1549,7 +1292,6 @@ extern "C" int aq3d_conv2d_sq16(const float *x, const void *params, const aq3d_c
                        (const float *)(base + l.amaxw), g->Cout, K, (float)((1 << (w_bits - 1)) - 1), wf, wstep);
     aq3d_conv2d_problem q;
     q.weight_split = nullptr;
-    q.kernel = 0;
     q.x = x; q.weight_or_params = wf; q.geom = g; q.bias = bias; q.post_scale = post_scale; q.post_shift = post_shift;
     q.y = y; q.pieces_out = nullptr; q.pieces_ld = 0; q.pieces_mode = 0;
     ConvGroup grp;
@@ -1571,7 +1313,6 @@ extern "C" int aq3d_conv2d_f32(const float *x, const float *weight, const aq3d_c
     AQ3D_REQUIRE(g, "aq3d_conv2d_f32: null argument");
     aq3d_conv2d_problem q;
     q.weight_split = nullptr;
-    q.kernel = 0;
     q.x = x; q.weight_or_params = weight; q.geom = g; q.bias = bias; q.post_scale = post_scale; q.post_shift = post_shift;
     q.y = y; q.pieces_out = pieces_out; q.pieces_ld = pieces_ld; q.pieces_mode = 0;
     return aq3d_conv2d_f32_group(&q, 1, stream_);

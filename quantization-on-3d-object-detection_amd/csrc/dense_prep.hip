@@ -40,7 +40,7 @@ extern "C" int aq3d_scatter_dense(const float *feats, const int32_t *coords, con
     AQ3D_REQUIRE(feats && coords && count && out, "aq3d_scatter_dense: null argument");
     AQ3D_REQUIRE(C > 0 && shape[0] > 0 && shape[1] > 0 && shape[2] > 0 && batch_size > 0, "aq3d_scatter_dense: bad sizes");
     const size_t bytes = (size_t)batch_size * shape[1] * shape[2] * C * shape[0] * sizeof(float);
-    hipMemsetAsync(out, 0, bytes, stream);
+    aq3d_zero_async(out, bytes, stream);
     hipLaunchKernelGGL(scatter_dense_kernel, dim3(aq3d_grid((int64_t)cap * C, 256)), dim3(256), 0, stream, feats, coords,
                        count, cap, C, shape[0], shape[1], shape[2], batch_size, out);
     AQ3D_CHECK_LAUNCH("aq3d_scatter_dense");

@@ -829,7 +829,7 @@ extern "C" int aq3d_level_from_points(const float *points, int32_t n_points, con
         aq3d_set_error("aq3d_level_from_points: workspace %zu < %zu bytes", workspace_bytes, aq3d_index_workspace_bytes(L.cap, L.words, n_points));
         return AQ3D_ERR_WORKSPACE;
     }
-    hipMemsetAsync(L.bits, 0, (size_t)L.words * 8, stream);
+    aq3d_zero_async(L.bits, (size_t)L.words * 8, stream);
     if (n_points > 0)
         hipLaunchKernelGGL(ix_mark_points, dim3(aq3d_grid(n_points, IX_BLOCK)), dim3(IX_BLOCK), 0, stream, points, n_points, q, L, ws.pcell);
     hipLaunchKernelGGL(ix_count, dim3(aq3d_div_up(ix_words_grid(L), IX_CPB)), dim3(IX_BLOCK), 0, stream, L, ws, ix_words_grid(L));
@@ -854,7 +854,7 @@ extern "C" int aq3d_level_from_coords(const int32_t *coords_in, int32_t n, const
         aq3d_set_error("aq3d_level_from_coords: workspace %zu < %zu bytes", workspace_bytes, aq3d_index_workspace_bytes(L.cap, L.words, n));
         return AQ3D_ERR_WORKSPACE;
     }
-    hipMemsetAsync(L.bits, 0, (size_t)L.words * 8, stream);
+    aq3d_zero_async(L.bits, (size_t)L.words * 8, stream);
     if (n > 0) hipLaunchKernelGGL(ix_mark_coords, dim3(aq3d_grid(n, IX_BLOCK)), dim3(IX_BLOCK), 0, stream, coords_in, n, L, ws.pcell);
     hipLaunchKernelGGL(ix_count, dim3(aq3d_div_up(ix_words_grid(L), IX_CPB)), dim3(IX_BLOCK), 0, stream, L, ws, ix_words_grid(L));
     ix_number_rows(L, ws, stream);

@@ -151,7 +151,6 @@ class Engine:
         self.steps = []
         self.tensors = {}
         self.sparse_w16 = bool(getattr(det, "sparse_w16", False))
-        self.i8_kernel = int(os.environ.get("AQ3D_I8_KERNEL", "0"))       # aq3d_conv2d_problem.kernel of the int8 dense convs (A/B runs)
         self._head_args = {}
         self._force_rows = False     # teacher-forced tests: run the rows-only quantiser even where a producer epilogue does it
         if isinstance(det.backbone_3d, VoxelResBackBone8xVoxelNeXt):
@@ -802,7 +801,7 @@ class Engine:
                     po = self.arena.view(r["pieces_out"][0], (16, r["pieces_out"][1]))
                 out.append(dict(x=r["x"][b], w=r["params"] if kind == "i8" else r["weight"], g=r["geom"], bias=r["bias"],
                                 post_scale=r["post_scale"], post_shift=r["post_shift"], y=r["out"][b], pieces_out=po,
-                                pieces_mode=r["pieces_out"][2] if r["pieces_out"] is not None else 0, kernel=self.i8_kernel))
+                                pieces_mode=r["pieces_out"][2] if r["pieces_out"] is not None else 0))
             return out
         G["problems"] = problems        # resolved after the arena exists (first run)
         G["conv_args"] = None
@@ -1072,12 +1071,11 @@ class Engine:
                 if B > 1:
                     for args in self._batched_problems(rec.setdefault("_batch_args", {}), lambda b: [dict(
                             x=x[b], w=rec["params"], g=g, bias=rec["bias"], post_scale=rec["post_scale"], post_shift=rec["post_shift"],
-                            y=out[b], pieces_out=po, pieces_mode=rec["pieces_out"][2] if po is not None else 0,
-                            kernel=self.i8_kernel)], B):
+                            y=out[b], pieces_out=po, pieces_mode=rec["pieces_out"][2] if po is not None else 0)], B):
                         ops.conv2d_i8_group(args)
                 else:
                     ops.conv2d_i8(x[0], rec["params"], g, rec["bias"], rec["post_scale"], rec["post_shift"], out=out[0],
-                                  pieces_out=po, pieces_mode=rec["pieces_out"][2] if po is not None else 0, kernel=self.i8_kernel)
+                                  pieces_out=po, pieces_mode=rec["pieces_out"][2] if po is not None else 0)
         else:
             cal = rec.get("calib")
             if cal is not None:

@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
 
-ABI_VERSION = 19
+ABI_VERSION = 18
 
 
 class Aq3dError(RuntimeError):
@@ -48,7 +48,7 @@ class HeadProblem(Structure):
 class Conv2dProblem(Structure):
     _fields_ = [("x", c_void_p), ("weight_or_params", c_void_p), ("geom", POINTER(Conv2dGeom)), ("bias", c_void_p),
                 ("post_scale", c_void_p), ("post_shift", c_void_p), ("y", c_void_p), ("pieces_out", c_void_p),
-                ("pieces_ld", c_int32), ("pieces_mode", c_int32), ("weight_split", c_void_p), ("kernel", c_int32)]
+                ("pieces_ld", c_int32), ("pieces_mode", c_int32), ("weight_split", c_void_p)]
 
 
 class SpconvProblem(Structure):

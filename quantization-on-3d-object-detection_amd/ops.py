@@ -401,16 +401,11 @@ def sq_prep(pieces, weight_k, w_colmax, g, alpha, params=None, w_bits=8, a_bits=
     return params
 
 
-def conv2d_i8(x, params, g, bias=None, post_scale=None, post_shift=None, out=None, pieces_out=None, pieces_mode=0, kernel=0):
-    """pieces_out: optional f32 [16, ld] accumulator that receives the piece abs-max of the OUTPUT (fused, caller-zeroed).
-    kernel: aq3d_conv2d_problem.kernel (0 = the library's choice, 1 = per-step staging, 2 / 3 = tap planes, small / large tile)."""
+def conv2d_i8(x, params, g, bias=None, post_scale=None, post_shift=None, out=None, pieces_out=None, pieces_mode=0):
+    """pieces_out: optional f32 [16, ld] accumulator that receives the piece abs-max of the OUTPUT (fused, caller-zeroed)."""
     L = _lib.load()
     Ho, Wo = out_hw(g)
     y = out if out is not None else torch.empty((Ho, Wo, g.out_ld), dtype=f32, device=x.device)
-    if kernel:
-        conv2d_i8_group(conv_problems([dict(x=x, w=params, g=g, bias=bias, post_scale=post_scale, post_shift=post_shift, y=y,
-                                            pieces_out=pieces_out, pieces_mode=pieces_mode, kernel=kernel)]))
-        return y
     check(L.aq3d_conv2d_i8(_p(x), _p(params), ctypes.byref(g), _p(bias), _p(post_scale), _p(post_shift), _p(y),
                            _p(pieces_out), 0 if pieces_out is None else pieces_out.shape[1], int(pieces_mode), _stream()), "aq3d_conv2d_i8")
     return y
@@ -442,7 +437,6 @@ def conv_problems(recs):
         q.y, q.pieces_out = _addr(r["y"]), _addr(po)
         q.pieces_ld, q.pieces_mode = (0 if po is None else int(po.shape[1])), int(r.get("pieces_mode", 0))
         q.weight_split = _addr(r.get("w_split"))
-        q.kernel = int(r.get("kernel", 0))
     return arr
 
 
