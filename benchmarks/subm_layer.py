@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_GBS, F16_TFLOPS = 8000.0, 2500.0
+HBM_GBS, I8_TOPS = 8000.0, 5000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s; dense int8 MFMA = 2 x the 2.5 PF of bf16
 
 
 def _morton_key(idx):
@@ -145,7 +145,11 @@ def main():
                    "voxels": m, "pairs": pairs, "us_per_layer": us, "us_prep": us_prep, "us_conv": us_conv,
                    "algorithmic_bytes": byts, "algorithmic_GBps": byts / us / 1e3, "frac_hbm": byts / us / 1e3 / HBM_GBS,
                    "conv_only_GBps": b_conv / us_conv / 1e3, "conv_only_frac_hbm": b_conv / us_conv / 1e3 / HBM_GBS,
-                   "useful_TFLOPs": flops / us / 1e6, "frac_mfma_f16": 2 * flops / us_conv / 1e6 / F16_TFLOPS, "voxels_per_s": m / us * 1e6}
+                   # USEFUL ops (2 x pairs x C x C) over the int8 matrix peak — the pipe the layer runs on since round 3; the planes of the
+                   # fixed-point weights (3, or 2 with --w16) are issued work, listed beside it, never as throughput
+                   "useful_TOPs": flops / us / 1e6, "conv_only_useful_TOPs": flops / us_conv / 1e6,
+                   "frac_mfma_i8_useful": flops / us_conv / 1e6 / I8_TOPS, "weight_planes": 2 if args.w16 else 3,
+                   "issued_TOPs_lower_bound": (2 if args.w16 else 3) * flops / us_conv / 1e6, "voxels_per_s": m / us * 1e6}
             if args.cpu and m_req == args.voxels[0]:
                 xa, _ = OS.qconv_act(x.cpu().numpy(), 8, cw=True)
                 nb = nbr.cpu().numpy()

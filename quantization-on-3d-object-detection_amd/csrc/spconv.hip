@@ -609,6 +609,11 @@ __global__ __launch_bounds__(256) void spconv_small_kernel(SpconvGroup grp, int 
 // weights of a kernel offset are wave-uniform scalar operands), fp32 fma chain in (offset, channel) order — the same chain
 // as the MFMA kernel and the oracle's per-offset matmul. (16 channels per thread — every input gathered once instead of once per
 // channel quad — measured slower, 46 against 37 us: the kernel is a latency chain and the four quads are its parallelism.)
+// Round 4 tried to turn the six dependent memory rounds into two (gather table through LDS as one coalesced block, all 27 x Cin
+// feature loads in flight, eight channels per thread): 57 us with branches around the loads, 57 us with bounded loads, 224 us with
+// the weights in LDS (512 VGPRs + 2.9 KB of scratch) against this kernel's 34 us. What the variants had in common: time followed the
+// per-thread length of the (scalar weight load -> fma) chain, 540 operands here, 1080 there — the chain, not the gathers, is the
+// floor of a plain-VALU formulation (4dc3b90 .. this commit's parent hold the code).
 template <int CIN>
 __global__ __launch_bounds__(256) void spconv_stem_kernel(SpconvArgs a, int cout) {
     int n = *a.count_out;
@@ -685,101 +690,6 @@ __global__ __launch_bounds__(256) void spconv_stem_kernel(SpconvArgs a, int cout
     }
 }
 
-// Round 4: the 3 x 3 x 3 case in TWO dependent memory rounds instead of six. The kernel above is a latency chain (three chunks of
-// nine offsets, each a table load followed by the feature loads that depend on it; ~2 waves per SIMD to hide it: 34 us for 30 k
-// rows, 2 % of what its 5.8 MB would cost at the HBM roof). Here the 256 x 27 table entries of a workgroup arrive as ONE coalesced
-// block through LDS, every lane then issues the feature loads of the neighbours it HAS (a LiDAR voxel has ~3 of its 27; a missing
-// one is a skipped branch, not a bounded load that still occupies the address pipeline), all in flight together, and the fma
-// chain runs in the same (offset, channel) order as before — bit-identical sums. NCH output channels per thread: the rows are
-// gathered cout / NCH times, the chain per thread is NCH / 4 times longer.
-template <int CIN, int NCH>
-__global__ __launch_bounds__(256) void spconv_stem27_kernel(SpconvArgs a, int cout) {
-    constexpr int KV = 27;
-    __shared__ int s_nbr[256 * KV];
-    int n = *a.count_out;
-    if (n > a.cap_out) n = a.cap_out;
-    const int row0 = blockIdx.x * 256;
-    if (row0 >= n) return;                                   // (uniform) buffers are sized for the capacity, not the frame
-    const int row = row0 + threadIdx.x;
-    const int o0 = blockIdx.y * NCH;
-    const float *x = static_cast<const float *>(a.feats_in);
-    const float *w = static_cast<const float *>(a.weight);        // [kvol][cout][CIN]
-    {
-        const int valid = (n - row0 < 256 ? n - row0 : 256) * KV;
-        const int *src = a.nbr + (size_t)row0 * KV;
-#pragma unroll
-        for (int i = 0; i < KV; ++i) {
-            const int e = i * 256 + threadIdx.x;
-            s_nbr[e] = e < valid ? src[e] : -1;
-        }
-    }
-    __syncthreads();
-    float xv[KV][CIN];
-#pragma unroll
-    for (int u = 0; u < KV; ++u) {
-        const int sr = s_nbr[threadIdx.x * KV + u];          // stride 27 words: conflict-free
-#pragma unroll
-        for (int c = 0; c < CIN; ++c) xv[u][c] = 0.f;
-        if (sr >= 0) {
-            const float *p = x + (size_t)sr * CIN;
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) xv[u][c] = p[c];
-        }
-    }
-    float acc[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) acc[j] = 0.f;
-#pragma unroll
-    for (int u = 0; u < KV; ++u) {
-        const float *wk = w + ((size_t)u * cout + o0) * CIN;      // wave-uniform
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            float t = 0.f;
-#pragma unroll
-            for (int c = 0; c < CIN; ++c) t = __fmaf_rn(xv[u][c], wk[j * CIN + c], t);
-            acc[j] = __fadd_rn(acc[j], t);
-        }
-    }
-    float mx[NCH];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) mx[j] = 0.f;
-    if (row < n) {
-        float out[NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int o = o0 + j;
-            float v = acc[j];
-            if (a.bias) v = __fadd_rn(v, a.bias[o]);
-            if (a.post_scale) v = __fadd_rn(__fmul_rn(v, a.post_scale[o]), a.post_shift[o]);
-            if (a.residual) v = __fadd_rn(v, a.residual[(size_t)row * cout + o]);
-            if (a.relu) v = fmaxf(v, 0.f);
-            out[j] = v;
-            if (a.next_codes) {       // cout < 64: identity code layout
-                float q = rintf(__fmul_rn(v, a.next_scale[o]));
-                q = fminf(fmaxf(q, -a.next_qmax - 1.f), a.next_qmax);
-                a.next_codes[(size_t)row * cout + o] = (int8_t)(int)q;
-            }
-            mx[j] = fabsf(v);
-        }
-        float4 *dst = reinterpret_cast<float4 *>(a.feats_out + (size_t)row * cout + o0);
-#pragma unroll
-        for (int j = 0; j < NCH; j += 4) dst[j / 4] = make_float4(out[j], out[j + 1], out[j + 2], out[j + 3]);
-    }
-    if (a.absmax_out) {
-        __shared__ float red[4][NCH];
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const float m = aq3d_wave_max(mx[j]);
-            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = m;
-        }
-        __syncthreads();
-        if (threadIdx.x < NCH) {
-            const float m = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
-            if (m > a.absmax_out[o0 + threadIdx.x]) aq3d_atomic_max_pos(&a.absmax_out[o0 + threadIdx.x], m);
-        }
-    }
-}
-
 static int spconv_group_impl(const aq3d_spconv_problem *probs, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
                              int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, const float *next_scale,
                              int8_t *next_codes, float next_qmax, void *stream_);
@@ -841,16 +751,6 @@ static int spconv_group_impl(const aq3d_spconv_problem *probs, int32_t n, int32_
     }
     for (int i = n; i < AQ3D_SPCONV_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     const SpconvArgs &a = grp.p[0];
-    if (n == 1 && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && cin <= 8 && kvol == 27 && (cout & 7) == 0 && cout <= 64) {
-        const dim3 grid(aq3d_div_up(cap_out, 256), cout / 8);
-        switch (cin) {
-#define AQ3D_STEM27(C_) case C_: hipLaunchKernelGGL((spconv_stem27_kernel<C_, 8>), grid, dim3(256), 0, stream, a, cout); break;
-            AQ3D_STEM27(1) AQ3D_STEM27(2) AQ3D_STEM27(3) AQ3D_STEM27(4) AQ3D_STEM27(5) AQ3D_STEM27(6) AQ3D_STEM27(7) AQ3D_STEM27(8)
-#undef AQ3D_STEM27
-        }
-        AQ3D_CHECK_LAUNCH("aq3d_spconv(stem27)");
-        return AQ3D_OK;
-    }
     if (n == 1 && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && cin <= 8 && (cout & 3) == 0 && cout <= 64) {
         const dim3 grid(aq3d_div_up(cap_out, 256), cout / 4);
         switch (cin) {
