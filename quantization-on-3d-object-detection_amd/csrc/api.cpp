@@ -13,4 +13,4 @@ void aq3d_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *aq3d_last_error_string(void) { return g_err; }
-extern "C" int aq3d_abi_version(void) { return 18; }
+extern "C" int aq3d_abi_version(void) { return 19; }

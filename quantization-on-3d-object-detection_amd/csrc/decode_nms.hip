@@ -145,6 +145,23 @@ __device__ __forceinline__ float sigmoidf_dev(float x) { return __fdiv_rn(1.0f, 
 // chain of a head is a string of single-workgroup, latency-bound launches (~170 us per head), and the 6-head models (nuScenes
 // CenterPoint, VoxelNeXt) ran it six times back to back.
 #define AQ3D_MAX_HEADS 8
+// Rows [row0, row0 + rows) of a sparse head that one decode works on: every live row (sample < 0), or the rows of ONE sample of a
+// batch (voxelnext_head.py:418-488 decodes `for k in range(batch_size)` over spatial_indices[:, 0] == k). The rows of a raster-ordered
+// level are sorted by sample, so a sample is a contiguous range found by two binary searches; candidate indices are relative to row0
+// (the order, and with it every tie, is that of the sample run on its own) and decode_body adds row0 back.
+__device__ __forceinline__ void head_rows(const int *__restrict__ coords, const int *__restrict__ count, int cap, int sample, int &row0, int &rows) {
+    int n = *count;
+    n = n < 0 ? 0 : (n > cap ? cap : n);
+    row0 = 0;
+    rows = n;
+    if (sample < 0 || !coords) return;
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (coords[(size_t)mid * 4] < sample) lo = mid + 1; else hi = mid; }
+    row0 = lo;
+    hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (coords[(size_t)mid * 4] <= sample) lo = mid + 1; else hi = mid; }
+    rows = lo - row0;
+}
 __device__ __forceinline__ void topk_select_tail(const float *__restrict__ col, int hm_ld, int L, bool filtered, int cache_keys, int K, int Kpad,
                                                  u64 *sel, int *hist, int *sh, unsigned int *keys_s, unsigned int *idx_s,
                                                  u64 *__restrict__ out, const int cls);
@@ -361,7 +378,8 @@ __device__ __forceinline__ void topk_select_tail(const float *__restrict__ col, 
 struct TopkArgs {
     const float *hm;
     int hm_ld, L_static;
-    const int *count;
+    const int *count, *coords;
+    int sample;
     int K, Kpad, cache_keys, nclass;
     float score_thresh;
     u64 *out;
@@ -372,6 +390,12 @@ struct TopkBatch {
 __global__ __launch_bounds__(1024) void topk_per_class_kernel(TopkBatch b) {
     const TopkArgs &a = b.p[blockIdx.y];
     if ((int)blockIdx.x >= a.nclass) return;
+    if (a.count && a.sample >= 0) {       // one sample of a batch: its row range as a "dense map" of that many rows
+        int row0, rows;
+        head_rows(a.coords, a.count, a.L_static, a.sample, row0, rows);
+        topk_per_class_body(a.hm + (size_t)row0 * a.hm_ld, a.hm_ld, rows, nullptr, a.K, a.Kpad, a.cache_keys, a.score_thresh, a.out, (int)blockIdx.x);
+        return;
+    }
     topk_per_class_body(a.hm, a.hm_ld, a.L_static, a.count, a.K, a.Kpad, a.cache_keys, a.score_thresh, a.out, (int)blockIdx.x);
 }
 
@@ -391,6 +415,8 @@ __global__ __launch_bounds__(1024) void topk_per_class_kernel(TopkBatch b) {
 struct ScanArgs {
     const float *hm;
     const int *count;                                   // sparse head: live rows on the device (<= L); NULL for a dense map
+    const int *coords;                                  // sparse head: its rows' (b, z, y, x)
+    int sample;                                         // sparse head: -1 = every row, else the rows of this sample only (head_rows)
     int hm_ld, L, nclass, G, chunk, K, Kpad;            // L: H*W, or the row capacity of a sparse head
     float score_thresh;
     unsigned int *keys_all;                             // [nclass][L]
@@ -412,10 +438,10 @@ __global__ __launch_bounds__(1024) void topk_scan_kernel(ScanBatch b) {
     if (cls >= a.nclass || g >= a.G) return;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int per_wave = a.chunk >> 4;                       // multiple of 64
-    int L = a.L;
-    if (a.count) { L = *a.count; L = L < 0 ? 0 : (L > a.L ? a.L : L); }
+    int L = a.L, row0 = 0;
+    if (a.count) head_rows(a.coords, a.count, a.L, a.sample, row0, L);
     const int beg = g * a.chunk + w * per_wave, end = min(L, beg + per_wave);
-    const float *col = a.hm + cls;
+    const float *col = a.hm + cls + (size_t)row0 * a.hm_ld;
     const bool all_pass = a.score_thresh < 0.f;
     const unsigned int tkey = __float_as_uint(a.score_thresh);
     __shared__ int s_wcnt[16];
@@ -529,8 +555,8 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(ScanBatch b) {
     if (m > TK_SORT) {
         // crowded pivot bin: the general select over every pixel's key (keys_all -> LDS), ties by pixel order
         __syncthreads();        // hist[piv] read by everyone before the select reuses hist
-        int L = a.L;
-        if (a.count) { L = *a.count; L = L < 0 ? 0 : (L > a.L ? a.L : L); }
+        int L = a.L, row0 = 0;
+        if (a.count) head_rows(a.coords, a.count, a.L, a.sample, row0, L);
         const unsigned int *src = a.keys_all + (size_t)cls * a.L;
         for (int base = tid; base < L; base += 8 * 1024) {
             unsigned int t[8];
@@ -540,7 +566,7 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(ScanBatch b) {
             for (int u = 0; u < 8; ++u)
                 if (base + u * 1024 < L) keys_s[base + u * 1024] = t[u];
         }
-        topk_select_tail(a.hm + cls, a.hm_ld, L, false, 1, K, a.Kpad, sel, hist, hist + 256, keys_s, idx_s, a.out, cls);
+        topk_select_tail(a.hm + cls + (size_t)row0 * a.hm_ld, a.hm_ld, L, false, 1, K, a.Kpad, sel, hist, hist + 256, keys_s, idx_s, a.out, cls);
         return;
     }
     // 3. one pass over the candidates: higher bin -> selected, pivot bin -> composite into the sort buffer
@@ -603,6 +629,8 @@ struct DecodeParams {
     aq3d_decode_cfg c;
     const float *center, *center_z, *dim, *rot, *vel;
     const int *coords;      // sparse head: rows (b, z|0, y, x) of the voxels; NULL for a dense map
+    const int *count;       // sparse head: live rows
+    int cap, sample;        // sparse head: row capacity; -1 or the sample whose rows were ranked (candidate indices are relative to its first row)
 };
 
 __device__ __forceinline__ void decode_body(const u64 *__restrict__ cand, int ncand, int Npad, const DecodeParams &q,
@@ -612,6 +640,8 @@ __device__ __forceinline__ void decode_body(const u64 *__restrict__ cand, int nc
     u64 *keys = reinterpret_cast<u64 *>(smem_raw);  // [Npad] : score bits << 32 | ~position (position = class*K + rank)
     __shared__ int sh[16];
     const int K = q.c.K;
+    int row0 = 0;
+    if (q.coords && q.sample >= 0) { int rows_; head_rows(q.coords, q.count, q.cap, q.sample, row0, rows_); }
     DN_STAMP(1, 0);
     for (int i = threadIdx.x; i < Npad; i += blockDim.x) {
         u64 v = 0ull;
@@ -641,7 +671,7 @@ __device__ __forceinline__ void decode_body(const u64 *__restrict__ cand, int nc
         const u64 kv = keys[t];
         const unsigned cp = 0xffffffffu - (unsigned int)(kv & 0xffffffffull);
         label = (int)(cp >> 27);
-        const int pix = (int)(cp & 0x07ffffffu);
+        const int pix = (int)(cp & 0x07ffffffu) + row0;
         score = __uint_as_float((unsigned int)(kv >> 32));
         int yi, xi;
         if (q.coords) { yi = q.coords[(size_t)pix * 4 + 2]; xi = q.coords[(size_t)pix * 4 + 3]; }
@@ -732,7 +762,7 @@ static size_t decode_ws_min(const aq3d_decode_cfg *cfg) { return (size_t)cfg->nu
 struct DecodeProblem {
     const float *hm, *center, *center_z, *dim, *rot, *vel;
     const int32_t *coords, *count;
-    int32_t cap;
+    int32_t cap, sample;
     const aq3d_decode_cfg *cfg;
     float *boxes_out, *scores_out;
     int32_t *labels_out, *count_out;
@@ -770,6 +800,7 @@ static void launch_decode(const DecodeProblem *d, int n, hipStream_t stream) {
         multi = multi && w.multi && d[i].workspace_bytes >= need;
         ScanArgs &c = sb.p[i];
         char *ws = (char *)d[i].workspace;
+        c.coords = d[i].coords; c.sample = d[i].coords ? d[i].sample : -1;
         c.hm = d[i].hm; c.count = d[i].coords ? d[i].count : nullptr; c.hm_ld = d[i].cfg->hm_ld; c.L = (int)Ls; c.nclass = d[i].cfg->num_classes; c.G = w.G; c.chunk = w.chunk;
         c.K = d[i].cfg->K; c.Kpad = next_pow2(c.K); c.score_thresh = d[i].cfg->score_thresh;
         c.keys_all = (unsigned int *)(ws + w.keys_all); c.cand = (u64 *)(ws + w.cand);
@@ -787,11 +818,12 @@ static void launch_decode(const DecodeProblem *d, int n, hipStream_t stream) {
         if (cache_keys) lds1 += key_bytes;
         TopkArgs &t = tb.p[i];
         t.hm = d[i].hm; t.hm_ld = cfg->hm_ld; t.L_static = L; t.count = d[i].coords ? d[i].count : nullptr; t.K = K; t.Kpad = Kpad;
+        t.coords = d[i].coords; t.sample = d[i].coords ? d[i].sample : -1;
         t.cache_keys = cache_keys; t.nclass = cfg->num_classes; t.score_thresh = cfg->score_thresh; t.out = (u64 *)d[i].workspace;
         DecodeArgs &a = db.p[i];
         a.cand = (const u64 *)d[i].workspace; a.ncand = cfg->num_classes * K; a.Npad = next_pow2(a.ncand);
         a.q.c = *cfg; a.q.center = d[i].center; a.q.center_z = d[i].center_z; a.q.dim = d[i].dim; a.q.rot = d[i].rot; a.q.vel = d[i].vel;
-        a.q.coords = d[i].coords;
+        a.q.coords = d[i].coords; a.q.count = d[i].count; a.q.cap = d[i].cap; a.q.sample = d[i].coords ? d[i].sample : -1;
         a.boxes_out = d[i].boxes_out; a.scores_out = d[i].scores_out; a.labels_out = d[i].labels_out; a.count_out = d[i].count_out;
         lds1_max = lds1 > lds1_max ? lds1 : lds1_max;
         const size_t lds2 = (size_t)a.Npad * 8;
@@ -824,7 +856,7 @@ extern "C" int aq3d_center_decode(const float *hm, const float *center, const fl
                                   const float *rot, const float *vel, const aq3d_decode_cfg *cfg, float *boxes_out,
                                   float *scores_out, int32_t *labels_out, int32_t *count_out, void *workspace,
                                   size_t workspace_bytes, void *stream_) {
-    const DecodeProblem d = {hm, center, center_z, dim, rot, vel, nullptr, nullptr, 0, cfg, boxes_out, scores_out, labels_out, count_out,
+    const DecodeProblem d = {hm, center, center_z, dim, rot, vel, nullptr, nullptr, 0, -1, cfg, boxes_out, scores_out, labels_out, count_out,
                              workspace, workspace_bytes};
     const int rc = check_decode(d, "aq3d_center_decode");
     if (rc != AQ3D_OK) return rc;
@@ -838,7 +870,7 @@ extern "C" int aq3d_voxel_decode(const float *hm, const float *center, const flo
                                  const aq3d_decode_cfg *cfg, float *boxes_out, float *scores_out, int32_t *labels_out,
                                  int32_t *count_out, void *workspace, size_t workspace_bytes, void *stream_) {
     AQ3D_REQUIRE(coords, "aq3d_voxel_decode: null coords");
-    const DecodeProblem d = {hm, center, center_z, dim, rot, vel, coords, count, cap, cfg, boxes_out, scores_out, labels_out, count_out,
+    const DecodeProblem d = {hm, center, center_z, dim, rot, vel, coords, count, cap, -1, cfg, boxes_out, scores_out, labels_out, count_out,
                              workspace, workspace_bytes};
     const int rc = check_decode(d, "aq3d_voxel_decode");
     if (rc != AQ3D_OK) return rc;
@@ -1091,7 +1123,8 @@ extern "C" int aq3d_decode_nms_batch(const aq3d_head_problem *heads, int32_t n, 
         const aq3d_head_problem &h = heads[i];
         AQ3D_REQUIRE(h.cfg, "aq3d_decode_nms_batch: head %d: null cfg", i);
         const int nbox = h.cfg->has_vel ? 9 : 7;
-        d[i] = {h.hm, h.center, h.center_z, h.dim, h.rot, h.vel, h.coords, h.count, h.cap, h.cfg, h.cand_boxes, h.cand_scores, h.cand_labels,
+        AQ3D_REQUIRE(h.sample >= -1, "aq3d_decode_nms_batch: head %d: sample=%d", i, h.sample);
+        d[i] = {h.hm, h.center, h.center_z, h.dim, h.rot, h.vel, h.coords, h.count, h.cap, h.sample, h.cfg, h.cand_boxes, h.cand_scores, h.cand_labels,
                 h.cand_count, h.decode_workspace, h.decode_workspace_bytes};
         int rc = check_decode(d[i], "aq3d_decode_nms_batch(decode)");
         if (rc != AQ3D_OK) return rc;

@@ -423,7 +423,7 @@ class CenterPoint(Detector3DTemplate):
 
 class VoxelNeXt(CenterPoint):
     """pcdet/models/detectors/voxelnext.py:3-44 — same forward / post_processing shape as CenterPoint, fully sparse modules
-    (vfe → VoxelResBackBone8xVoxelNeXt → VoxelNeXtHead). One sample per forward in this build."""
+    (vfe → VoxelResBackBone8xVoxelNeXt → VoxelNeXtHead); batches are decoded sample by sample like the reference head does."""
 
 
 DETECTORS = {"CenterPoint": CenterPoint, "VoxelNeXt": VoxelNeXt}

@@ -268,6 +268,9 @@ class Engine:
         else:
             rec["weight"] = self._dev(np.transpose(padc(w), (1, 0, 2)))
             rec["w_dequant"] = None
+        if q2 is not None and rec["weight"].dtype == torch.int8 and cin == 128 and cout == 128:
+            # a weight-only 128 -> 128 layer (VoxelNeXt's head): the codes as fp16, once, instead of once per row tile and kernel offset
+            rec["weight"] = rec["weight_i8"].to(torch.float16).contiguous()        # AQ3D_W_I8H
         if rec["weight"].dtype == f32 and cin == 128 and cout == 128:
             # an un-quantised 128 -> 128 layer runs on the fp16 pipe with split operands: its weights are split once, here
             rec["weight"] = ops.split_weight(rec["weight"].reshape(kvol * cout, cin))        # f16 [kvol * cout, 2, cin]
@@ -447,8 +450,7 @@ class Engine:
                                       self.pc_range[:2], [float(v) for v in pp.POST_CENTER_LIMIT_RANGE],
                                       pp.SCORE_THRESH, ld["hm"], ld["center"])
             nb = 9 if has_vel else 7
-            B = self.batch_cap
-            assert B == 1, "the VoxelNeXt plan decodes one sample per forward"
+            B = self.batch_cap          # a batch is decoded sample by sample (voxelnext_head.py:418-488): aq3d_head_problem.sample
             rec = dict(outs=outs, cfg=cfg, has_vel=has_vel, nb=nb, K=K, level=oi,
                        thresh=float(nms.NMS_THRESH), pre=int(nms.NMS_PRE_MAXSIZE), post=int(nms.NMS_POST_MAXSIZE),
                        class_map=head.class_id_mapping_each_head[hi].to(dev).to(i32).contiguous(),
@@ -742,7 +744,7 @@ class Engine:
                 feats_in=r["x"]["buf"], weight=r["weight"], w_dequant=r["w_dequant"], bias=r["bias"], post_scale=r["post_scale"],
                 post_shift=r["post_shift"], nbr=nbr, count_out=lv["count"], feats_out=r["out"]["buf"],
                 absmax_out=self.arena.view(r["out"]["amax"]) if id(r["out"]) in read else None, cout_real=r["cout_real"]) for r in recs])
-            G["w_mode"] = ops.W_I8 if r0["weight"].dtype == torch.int8 else (ops.W_F16S if r0["weight"].dtype == torch.float16 else ops.W_F32)
+            G["w_mode"] = ops.weight_mode(r0["weight"], r0["w_dequant"])
         with _Timed(self, "spconv_c%d" % r0["cout"]):
             ops.spconv_group(G["args"], ops.ACT_F32, G["w_mode"], lv["cap"], self.levels[r0["x"]["level"]]["cap"], r0["cin"], r0["cout"],
                              r0["kvol"], r0["relu"])
@@ -1232,8 +1234,6 @@ class Engine:
     def _graph_ok(self, batch_dict, B):
         if not self.use_graph or self.timers is not None or "points" not in batch_dict:
             return False
-        if B > 1 and self.fully_sparse:
-            return False
         if self._calibrating is None:   # calibration forwards harvest statistics on the host between launches: eager only
             self._calibrating = any(r["quant"] is not None and r["quant"]["calib"] for r in self.sparse_convs) or \
                 any(r.get("calib") is not None for r in self.dense_convs)
@@ -1309,7 +1309,7 @@ class Engine:
                     self._bev_merge()
             elif kind == "voxel_decode_nms":
                 with _Timed(self, "decode_nms"):
-                    self._voxel_decode_nms()
+                    self._voxel_decode_nms(B)
 
     def _run_index(self, kind, arg):
         # "index_subm" / "index_head" only register tables at compile time: every table of a level is built with the level
@@ -1329,15 +1329,17 @@ class Engine:
         ops.level_merge(levels, scales, lv["index"], workspace=self.index_ws)
         ops.level_merge_sum(levels, [x["buf"] for x, _, _ in m["srcs"]], scales, lv["index"], feats_out=m["out"]["buf"])
 
-    def _voxel_decode_nms(self):
+    def _voxel_decode_nms(self, B=1):
         def make(hi, h, b):
             lv = self.levels[h["level"]]
             o = h["outs"]
             r = self._head_common(hi, h, b)
             r.update(hm=o["hm"]["buf"], center=o["center"]["buf"], center_z=o["center_z"]["buf"], dim=o["dim"]["buf"], rot=o["rot"]["buf"],
-                     vel=o["vel"]["buf"] if h["has_vel"] else None, coords=lv["coords"], count=lv["count"])
+                     vel=o["vel"]["buf"] if h["has_vel"] else None, coords=lv["coords"], count=lv["count"],
+                     sample=b if self.batch_cap > 1 else -1)      # the rows of sample b: the head level is raster-ordered (sorted by sample)
             return r
-        for args, _ in self._head_batches(1, make):
+        assert B == 1 or not self.levels[self.heads[0]["level"]]["index"].sorted_rows, "a batch needs the head level in raster order"
+        for args, _ in self._head_batches(B, make):
             ops.decode_nms_batch(args)
 
     # ------------------------------------------------------------------ results

@@ -9,7 +9,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_si
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libaq3d.so")
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class Aq3dError(RuntimeError):
@@ -37,7 +37,7 @@ class DecodeCfg(Structure):
 
 class HeadProblem(Structure):
     _fields_ = [("hm", c_void_p), ("center", c_void_p), ("center_z", c_void_p), ("dim", c_void_p), ("rot", c_void_p), ("vel", c_void_p),
-                ("coords", c_void_p), ("count", c_void_p), ("cap", c_int32), ("cfg", POINTER(DecodeCfg)),
+                ("coords", c_void_p), ("count", c_void_p), ("cap", c_int32), ("sample", c_int32), ("cfg", POINTER(DecodeCfg)),
                 ("cand_boxes", c_void_p), ("cand_scores", c_void_p), ("cand_labels", c_void_p), ("cand_count", c_void_p),
                 ("decode_workspace", c_void_p), ("decode_workspace_bytes", c_size_t), ("nms_thresh", c_float), ("nms_cap", c_int32),
                 ("post_max", c_int32), ("keep", c_void_p), ("keep_count", c_void_p), ("nms_workspace", c_void_p),

@@ -250,7 +250,17 @@ def quantize_rows(x, amax, count, bits=8, per_tensor=False, want_codes=True, wan
 
 
 ACT_F32, ACT_I8 = 0, 1
-W_F32, W_I8, W_F16S = 0, 1, 2
+W_F32, W_I8, W_F16S, W_I8H = 0, 1, 2, 3
+
+
+def weight_mode(weight, w_dequant):
+    """aq3d w_mode of a sparse-conv weight tensor: int8 codes | the codes expanded to fp16 (with a dequant vector) | fp32 split into fp16
+    planes | fp32."""
+    if weight.dtype == torch.int8:
+        return W_I8
+    if weight.dtype == torch.float16:
+        return W_I8H if w_dequant is not None else W_F16S
+    return W_F32
 FLAG_RELU, FLAG_SKIP_F32, FLAG_W16 = 1, 2, 4
 
 
@@ -261,7 +271,7 @@ def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequan
     L = _lib.load()
     cap_out, kvol = nbr.shape
     act_mode = ACT_I8 if feats_in.dtype == torch.int8 else ACT_F32
-    w_mode = W_I8 if weight.dtype == torch.int8 else (W_F16S if weight.dtype == torch.float16 else W_F32)
+    w_mode = weight_mode(weight, w_dequant)
     cin = feats_in.shape[1]
     assert weight.shape == ((kvol * cout, 2, cin) if w_mode == W_F16S else (kvol, cout, cin)), (tuple(weight.shape), (kvol, cout, cin))
     y = out if out is not None else torch.empty((cap_out, cout), dtype=f32, device=nbr.device)
@@ -587,6 +597,7 @@ def head_problems(recs):
         q.hm, q.center, q.center_z, q.dim, q.rot = _addr(r["hm"]), _addr(r["center"]), _addr(r["center_z"]), _addr(r["dim"]), _addr(r["rot"])
         q.vel, q.coords, q.count = _addr(r.get("vel")), _addr(r.get("coords")), _addr(r.get("count"))
         q.cap = 0 if r.get("coords") is None else int(r["coords"].shape[0])
+        q.sample = int(r.get("sample", -1))
         q.cfg = ctypes.pointer(r["cfg"])
         cb, cs, cl, cc = r["cand"]
         q.cand_boxes, q.cand_scores, q.cand_labels, q.cand_count = _addr(cb), _addr(cs), _addr(cl), _addr(cc)

