@@ -187,11 +187,8 @@ enum {
 enum {
     AQ3D_W_F32 = 0,    /* weight is f32 [kvol, Cout, Cin]                           */
     AQ3D_W_I8 = 1,     /* weight is i8 codes [kvol, Cout, Cin]; value = code * w_dequant[cout] */
-    AQ3D_W_F16S = 2,   /* fp32 weights already split into fp16 planes, f16 [kvol * Cout, 2, Cin] (aq3d_conv2d_split_weight of the f32
+    AQ3D_W_F16S = 2    /* fp32 weights already split into fp16 planes, f16 [kvol * Cout, 2, Cin] (aq3d_conv2d_split_weight of the f32
                         * [kvol * Cout, Cin] matrix): f32 activations, Cin = 128, Cout = 128 or 16 only */
-    AQ3D_W_I8H = 3     /* the AQ3D_W_I8 codes as fp16 [kvol, Cout, Cin] (every code is an exact fp16 integer; value = code * w_dequant[cout]):
-                        * f32 activations, Cin = Cout = 128 — the weight-only convs of VoxelNeXt's head, whose row tiles otherwise each
-                        * repeat the int8 -> fp16 expansion of the 128 x 128 weight tile per kernel offset. Same bits as AQ3D_W_I8 */
 };
 enum {
     AQ3D_FLAG_RELU = 1,

@@ -252,11 +252,9 @@ typedef _Float16 sp_f16x4 __attribute__((ext_vector_type(4)));
 // WSPLIT (with W32): the fp32 weights arrive already split, f16 [kvol][Cout][2][Cin] (aq3d_conv2d_split_weight; w_mode AQ3D_W_F16S) — the
 // split is the same for every row tile and kernel offset, and a 128 x 128 fp32 tile split by 256 threads per offset was most of the
 // un-quantised 128 -> 128 layer's 180 us.
-// WEXP (without W32): the int8 codes arrive expanded to fp16, [kvol][Cout][Cin] (w_mode AQ3D_W_I8H): the weight tile of an offset is
-// a plain 16-byte copy into LDS. The expansion was 64 conversions per thread, offset and row tile — more vector-ALU issue than the
-// activation split next to it, and together 2.4x the 1024 MFMA cycles they feed (VoxelNeXt's 36 weight-only 128 -> 128 convs: 0.70 of
-// 2.62 ms per frame in round 3).
-template <int CIN, int COUT, int WR, int WC, bool W32 = false, bool WSPLIT = false, bool WEXP = false>
+// (Round 4 measured the int8 codes pre-expanded to fp16 — the weight tile of an offset as a plain 16-byte copy into LDS instead of 64
+// conversions per thread: 95.5 against 92 us per grouped launch of VoxelNeXt's weight-only 128 -> 128 convs, i.e. nothing; removed.)
+template <int CIN, int COUT, int WR, int WC, bool W32 = false, bool WSPLIT = false>
 __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
     const SpconvArgs a = grp.p[blockIdx.y];
     constexpr int TM = 16 * WR;
@@ -339,16 +337,8 @@ __global__ __launch_bounds__(256) void spconv_f16w_kernel(SpconvGroup grp) {
                     *reinterpret_cast<sp_f16x4 *>(Bl + o * LDH + c4 * 4) = l;
                 }
             }
-            if (!W32 && WEXP) {
-                constexpr int C8 = CIN / 8;
-                const _Float16 *wk16 = static_cast<const _Float16 *>(a.weight) + (size_t)k * COUT * CIN;
-                for (int t = tid; t < COUT * C8; t += 256) {
-                    const int o = t / C8, c8 = t - o * C8;
-                    *reinterpret_cast<sp_f16x8 *>(Bh + o * LDH + c8 * 8) = *reinterpret_cast<const sp_f16x8 *>(wk16 + (size_t)o * CIN + c8 * 8);
-                }
-            }
             const int8_t *wk = static_cast<const int8_t *>(a.weight) + (size_t)k * COUT * CIN;
-            for (int t = tid; !W32 && !WEXP && t < COUT * C16; t += 256) {
+            for (int t = tid; !W32 && t < COUT * C16; t += 256) {
                 const int o = t / C16, c16 = t - o * C16;
                 const int4 q = *reinterpret_cast<const int4 *>(wk + (size_t)o * CIN + c16 * 16);
                 const int w[4] = {q.x, q.y, q.z, q.w};
@@ -449,7 +439,7 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
     } while (0)
     const bool f16w = true;
     if constexpr (CIN_PAD % 32 == 0) {
-        if (f16w && act_mode == AQ3D_ACT_F32 && (w_mode == AQ3D_W_I8 || w_mode == AQ3D_W_I8H) && a.cin == CIN_PAD) {
+        if (f16w && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_I8 && a.cin == CIN_PAD) {
             bool same = true;
             for (int i = 1; i < n; ++i) same = same && grp.p[i].cin == CIN_PAD;
             if constexpr (COUT == 128 && CIN_PAD == 128) if (same) {     // 64-row tiles (4 x 1 waves): the weights are re-streamed per tile (125 -> 100 us)
@@ -457,24 +447,14 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
                 constexpr size_t lds3 = (size_t)(2 * TM2 + COUT) * (CIN_PAD + 8) * 2 + (size_t)TM2 * 27 * 4 + (size_t)4 * COUT * 4;
                 const int tiles2 = aq3d_div_up(a.cap_out, TM2);
                 const int grid2 = tiles2 < 2048 ? (tiles2 < 1 ? 1 : tiles2) : 2048;
-                if (w_mode == AQ3D_W_I8H) {
-                    auto kern = spconv_f16w_kernel<CIN_PAD, COUT, 4, 1, false, false, true>;
-                    if (lds3 > 64 * 1024)
-                        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-                    hipLaunchKernelGGL(kern, dim3(grid2, n), dim3(256), lds3, stream, grp);
-                } else {
-                    auto kern = spconv_f16w_kernel<CIN_PAD, COUT, 4, 1>;
-                    if (lds3 > 64 * 1024)
-                        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-                    hipLaunchKernelGGL(kern, dim3(grid2, n), dim3(256), lds3, stream, grp);
-                }
+                auto kern = spconv_f16w_kernel<CIN_PAD, COUT, 4, 1>;
+                if (lds3 > 64 * 1024)
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                hipLaunchKernelGGL(kern, dim3(grid2, n), dim3(256), lds3, stream, grp);
                 AQ3D_CHECK_LAUNCH("aq3d_spconv");
                 return AQ3D_OK;
             }
-            if (w_mode == AQ3D_W_I8H) {
-                aq3d_set_error("aq3d_spconv: AQ3D_W_I8H needs Cin = Cout = 128");
-                return AQ3D_ERR_UNSUPPORTED;
-            }
+
             if (same) {
                 constexpr size_t lds2 = (size_t)(2 * TM + COUT) * (CIN_PAD + 8) * 2 + (size_t)TM * 27 * 4 + (size_t)WR * COUT * 4;
                 auto kern = spconv_f16w_kernel<CIN_PAD, COUT, WR, WC>;
@@ -508,10 +488,6 @@ static int spconv_launch_modes(const SpconvGroup &grp, int n, int act_mode, int 
                 return AQ3D_OK;
             }
         }
-    }
-    if (w_mode == AQ3D_W_I8H) {
-        aq3d_set_error("aq3d_spconv: AQ3D_W_I8H needs f32 activations and Cin = Cout = 128");
-        return AQ3D_ERR_UNSUPPORTED;
     }
     if (act_mode == AQ3D_ACT_I8 && w_mode == AQ3D_W_I8) AQ3D_SPCONV_GO(true, true);
     else if (act_mode == AQ3D_ACT_I8) AQ3D_SPCONV_GO(true, false);
@@ -736,7 +712,7 @@ extern "C" int aq3d_spconv(const void *feats_in, int32_t act_mode, const float *
     AQ3D_REQUIRE(cap_out > 0 && kvol >= 1 && kvol <= 27, "aq3d_spconv: cap_out=%d kvol=%d", cap_out, kvol);
     AQ3D_REQUIRE(cin >= 1 && cin <= 128, "aq3d_spconv: cin=%d not in 1..128", cin);
     AQ3D_REQUIRE(act_mode != AQ3D_ACT_I8 || ((cin % 16) == 0 && act_dequant), "aq3d_spconv: int8 activations need cin%%16==0 and act_dequant");
-    AQ3D_REQUIRE((w_mode != AQ3D_W_I8 && w_mode != AQ3D_W_I8H) || ((cin % 16) == 0 && w_dequant), "aq3d_spconv: int8 weights need cin%%16==0 and w_dequant");
+    AQ3D_REQUIRE(w_mode != AQ3D_W_I8 || ((cin % 16) == 0 && w_dequant), "aq3d_spconv: int8 weights need cin%%16==0 and w_dequant");
     AQ3D_REQUIRE((post_scale == nullptr) == (post_shift == nullptr), "aq3d_spconv: post_scale/post_shift must come together");
     aq3d_spconv_problem q;
     q.feats_in = feats_in; q.act_dequant = act_dequant; q.weight = weight; q.w_dequant = w_dequant; q.bias = bias;
@@ -764,8 +740,7 @@ static int spconv_group_impl(const aq3d_spconv_problem *probs, int32_t n, int32_
         const aq3d_spconv_problem &q = probs[i];
         AQ3D_REQUIRE(q.feats_in && q.weight && q.nbr && q.count_out && q.feats_out, "aq3d_spconv: null argument");
         AQ3D_REQUIRE(act_mode != AQ3D_ACT_I8 || ((cin % 16) == 0 && q.act_dequant), "aq3d_spconv: int8 activations need cin%%16==0 and act_dequant");
-        AQ3D_REQUIRE((w_mode != AQ3D_W_I8 && w_mode != AQ3D_W_I8H) || ((cin % 16) == 0 && q.w_dequant), "aq3d_spconv: int8 weights need cin%%16==0 and w_dequant");
-        AQ3D_REQUIRE(w_mode != AQ3D_W_I8H || (act_mode == AQ3D_ACT_F32 && cin == 128 && cout == 128), "aq3d_spconv: AQ3D_W_I8H needs f32 activations, Cin = Cout = 128");
+        AQ3D_REQUIRE(w_mode != AQ3D_W_I8 || ((cin % 16) == 0 && q.w_dequant), "aq3d_spconv: int8 weights need cin%%16==0 and w_dequant");
         AQ3D_REQUIRE((q.post_scale == nullptr) == (q.post_shift == nullptr), "aq3d_spconv: post_scale/post_shift must come together");
         AQ3D_REQUIRE(w_mode != AQ3D_W_F16S || (act_mode == AQ3D_ACT_F32 && cin == 128 && (cout == 128 || cout == 16)),
                      "aq3d_spconv: pre-split fp16 weight planes are taken for f32 activations, cin = 128, cout = 128 | 16 only");

@@ -268,9 +268,6 @@ class Engine:
         else:
             rec["weight"] = self._dev(np.transpose(padc(w), (1, 0, 2)))
             rec["w_dequant"] = None
-        if q2 is not None and rec["weight"].dtype == torch.int8 and cin == 128 and cout == 128:
-            # a weight-only 128 -> 128 layer (VoxelNeXt's head): the codes as fp16, once, instead of once per row tile and kernel offset
-            rec["weight"] = rec["weight_i8"].to(torch.float16).contiguous()        # AQ3D_W_I8H
         if rec["weight"].dtype == f32 and cin == 128 and cout == 128:
             # an un-quantised 128 -> 128 layer runs on the fp16 pipe with split operands: its weights are split once, here
             rec["weight"] = ops.split_weight(rec["weight"].reshape(kvol * cout, cin))        # f16 [kvol * cout, 2, cin]
@@ -744,7 +741,7 @@ class Engine:
                 feats_in=r["x"]["buf"], weight=r["weight"], w_dequant=r["w_dequant"], bias=r["bias"], post_scale=r["post_scale"],
                 post_shift=r["post_shift"], nbr=nbr, count_out=lv["count"], feats_out=r["out"]["buf"],
                 absmax_out=self.arena.view(r["out"]["amax"]) if id(r["out"]) in read else None, cout_real=r["cout_real"]) for r in recs])
-            G["w_mode"] = ops.weight_mode(r0["weight"], r0["w_dequant"])
+            G["w_mode"] = ops.W_I8 if r0["weight"].dtype == torch.int8 else (ops.W_F16S if r0["weight"].dtype == torch.float16 else ops.W_F32)
         with _Timed(self, "spconv_c%d" % r0["cout"]):
             ops.spconv_group(G["args"], ops.ACT_F32, G["w_mode"], lv["cap"], self.levels[r0["x"]["level"]]["cap"], r0["cin"], r0["cout"],
                              r0["kvol"], r0["relu"])

@@ -250,17 +250,7 @@ def quantize_rows(x, amax, count, bits=8, per_tensor=False, want_codes=True, wan
 
 
 ACT_F32, ACT_I8 = 0, 1
-W_F32, W_I8, W_F16S, W_I8H = 0, 1, 2, 3
-
-
-def weight_mode(weight, w_dequant):
-    """aq3d w_mode of a sparse-conv weight tensor: int8 codes | the codes expanded to fp16 (with a dequant vector) | fp32 split into fp16
-    planes | fp32."""
-    if weight.dtype == torch.int8:
-        return W_I8
-    if weight.dtype == torch.float16:
-        return W_I8H if w_dequant is not None else W_F16S
-    return W_F32
+W_F32, W_I8, W_F16S = 0, 1, 2
 FLAG_RELU, FLAG_SKIP_F32, FLAG_W16 = 1, 2, 4
 
 
@@ -271,7 +261,7 @@ def spconv(feats_in, weight, nbr, count_out, cout, *, act_dequant=None, w_dequan
     L = _lib.load()
     cap_out, kvol = nbr.shape
     act_mode = ACT_I8 if feats_in.dtype == torch.int8 else ACT_F32
-    w_mode = weight_mode(weight, w_dequant)
+    w_mode = W_I8 if weight.dtype == torch.int8 else (W_F16S if weight.dtype == torch.float16 else W_F32)
     cin = feats_in.shape[1]
     assert weight.shape == ((kvol * cout, 2, cin) if w_mode == W_F16S else (kvol, cout, cin)), (tuple(weight.shape), (kvol, cout, cin))
     y = out if out is not None else torch.empty((cap_out, cout), dtype=f32, device=nbr.device)
