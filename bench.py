@@ -582,7 +582,7 @@ def main():
 
     if rank == 0:
         traffic, traffic_meta = {}, None
-        for cand in ("profiles/r03/pmc_traffic.json", "profiles/pmc_traffic.json"):
+        for cand in ("profiles/r04/pmc_traffic.json", "profiles/r03/pmc_traffic.json", "profiles/pmc_traffic.json"):
             # HBM-side bytes per launch measured with rocprofv3 --pmc in a SEPARATE run of this command (scratch/prof_all.sh); the file
             # says at which commit (`_commit`) — it is evidence of that build, not of this run
             try:

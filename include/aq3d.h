@@ -134,6 +134,11 @@ int64_t aq3d_level_words(const int32_t shape[3], int32_t batch);
  * workspace serves every call that is ordered on one stream. */
 size_t aq3d_index_workspace_bytes(int32_t max_cap, int64_t max_words, int32_t max_points);
 
+/* aq3d_level_from_points / aq3d_level_from_coords REBUILD a level in place. They do not zero its bitmap (an 11.6 MB fill for a Waymo
+ * grid that holds 30 000 voxels): they clear the words of the site set the level currently describes — coords[0 .. count). So on
+ * entry bits, coords, count and total must be consistent: all zero (a freshly allocated level) or as a builder left them. A level
+ * whose previous build overflowed its row capacity (total[0] > cap) is zeroed as a whole. */
+
 /* Hard voxelization + mean VFE straight into an index level (replaces spconv's Point2VoxelCPU3d.point_to_voxel as called
  * from pcdet/datasets/processor/data_processor.py:45-61, + MeanVFE, vfe/mean_vfe.py:25-29, for the whole batch at once):
  *   points f32 [n_points, cfg->point_stride]; with cfg->batch_col the sample index is column 0, else batch_index.

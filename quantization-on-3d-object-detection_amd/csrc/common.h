@@ -42,7 +42,7 @@ static inline void aq3d_zero_async(void *p, size_t bytes, hipStream_t stream) {
     if (bytes == 0) return;
     const size_t n16 = bytes / 16;
     const size_t blocks = n16 ? (n16 + 255) / 256 : 1;
-    hipLaunchKernelGGL(aq3d_zero_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, stream, (uint4 *)p, n16, (int)(bytes % 16));
+    hipLaunchKernelGGL(aq3d_zero_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, stream, (uint4 *)p, n16, (int)(bytes % 16));
 }
 
 static inline int aq3d_grid(int64_t work, int block, int max_blocks = 2048) {

@@ -49,6 +49,10 @@ def measure(skip):
         model(dict(batches[0]))          # one complete frame first: index levels, tables and every buffer hold valid (then stale) data
     for n in FAMILIES.get(skip, []):
         setattr(ops, n, (lambda *a, **k: k.get("out")))
+    if skip.startswith("dup:"):          # the family launched TWICE per frame: the cross-check of the removal figure
+        for n in FAMILIES[skip[4:]]:
+            f = orig[n]
+            setattr(ops, n, (lambda f_: (lambda *a, **k: (f_(*a, **k), f_(*a, **k))[1]))(f))
     run(40)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -63,7 +63,7 @@ def capture(stream, fn, reps):
             fn()
     return g
 B_SEQS["level_from_points"](); torch.cuda.synchronize()
-gA = capture(sA, lambda: ops.conv2d_i8(x, params, geom, out=y, kernel=1), NA)
+gA = capture(sA, lambda: ops.conv2d_i8(x, params, geom, out=y), NA)
 def time_A(gB, n=30):
     stop = [False]
     def spin():
@@ -96,3 +96,29 @@ for name, fn in B_SEQS.items():
         sB.synchronize()
         tb = (time.perf_counter() - t0) / 50 * 1e6
     print(json.dumps({"B": name, "B_alone_us": round(tb, 1), "A_next_to_B_us": round(time_A(gB), 2)}), flush=True)
+
+
+# ---- the other direction: how long does each index sequence take while convs of ANOTHER stream keep the chip busy?
+def time_B(gB, busy, n=30):
+    stop = [False]
+    def spin():
+        with torch.cuda.stream(sA):
+            while not stop[0]:
+                gA.replay()
+                sA.synchronize()
+    th = None
+    if busy:
+        th = threading.Thread(target=spin); th.start(); time.sleep(0.05)
+    with torch.cuda.stream(sB):
+        gB.replay(); sB.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            gB.replay()
+            sB.synchronize()
+        dt = time.perf_counter() - t0
+    if th is not None:
+        stop[0] = True; th.join()
+    return dt / n * 1e6
+for name in ("level_from_points", "level_downsample", "level_neighbors", "level_from_coords_30k", "zero_bitmap_11.6MB"):
+    gB = capture(sB, B_SEQS[name], 1)
+    print(json.dumps({"B": name, "B_alone_us_incl_launch": round(time_B(gB, False), 1), "B_next_to_20_convs_in_flight_us": round(time_B(gB, True), 1)}), flush=True)
