@@ -35,6 +35,7 @@ struct IxWs {
     int *sstart;        // [batch + 1] rank of the first site of every sample
     int *cls_tot;       // [128] sites per class
     int *chunk_sums;    // [words / 256 + 1]
+    int *chunk_flag;    // [words / 256 + 1] level-0 builders: 1 = some point / voxel marked a word of the chunk (everything else skips the empty ones)
     int *cell_of_rank;  // [cap]
     int *hist;          // [(cap / 256 + 1) * 128]
     int *pcell;         // [points]
@@ -52,7 +53,7 @@ extern "C" int64_t aq3d_level_words(const int32_t shape[3], int32_t batch) {
 
 extern "C" size_t aq3d_index_workspace_bytes(int32_t max_cap, int64_t max_words, int32_t max_points) {
     size_t b = 256 + ix_align((IX_MAX_BATCH + 1) * 4) + 512;
-    b += ix_align(((size_t)max_words / IX_BLOCK + 2) * 4);
+    b += 2 * ix_align(((size_t)max_words / IX_BLOCK + 2) * 4);
     b += ix_align((size_t)max_cap * 4);
     b += ix_align(((size_t)max_cap / IX_BLOCK + 2) * 128 * 4);
     b += 2 * ix_align((size_t)(max_points > 0 ? max_points : 1) * 4);
@@ -68,6 +69,7 @@ static bool ix_carve(void *ws, size_t bytes, int cap, int64_t words, int points,
     w->sstart = (int *)p;       p += ix_align((IX_MAX_BATCH + 1) * 4);
     w->cls_tot = (int *)p;      p += 512;
     w->chunk_sums = (int *)p;   p += ix_align(((size_t)words / IX_BLOCK + 2) * 4);
+    w->chunk_flag = (int *)p;   p += ix_align(((size_t)words / IX_BLOCK + 2) * 4);
     w->cell_of_rank = (int *)p; p += ix_align((size_t)cap * 4);
     w->hist = (int *)p;         p += ix_align(((size_t)cap / IX_BLOCK + 2) * 128 * 4);
     w->pcell = (int *)p;        p += ix_align((size_t)(points > 0 ? points : 1) * 4);
@@ -212,7 +214,8 @@ struct MarkParams {
 // (Round 4, scratch/ablate.py: that fill, 8 us on its own, cost 0.25 ms of every 1.04 ms frame interval with four frames in flight;
 // no other kernel of the frame is as expensive per microsecond.) A builder that overflowed the row capacity left sites without a
 // coords row: then (total > cap) every workgroup falls back to zeroing the whole bitmap.
-__global__ __launch_bounds__(IX_BLOCK) void ix_clear_prev(Lv L) {
+__global__ __launch_bounds__(IX_BLOCK) void ix_clear_prev(Lv L, int *__restrict__ chunk_flag, int nchunks) {
+    for (int i = blockIdx.x * IX_BLOCK + threadIdx.x; i < nchunks; i += gridDim.x * IX_BLOCK) chunk_flag[i] = 0;
     const int total = L.total[0];
     if (total > L.cap) {
         for (size_t w = (size_t)blockIdx.x * IX_BLOCK + threadIdx.x; w < (size_t)L.words; w += (size_t)gridDim.x * IX_BLOCK) L.bits[w] = 0ull;
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_clear_prev(Lv L) {
 }
 
 __global__ __launch_bounds__(IX_BLOCK) void ix_mark_points(const float *__restrict__ points, int n, MarkParams q, Lv L,
-                                                           int *__restrict__ pcell) {
+                                                           int *__restrict__ pcell, int *__restrict__ chunk_flag) {
     for (int i = blockIdx.x * IX_BLOCK + threadIdx.x; i < n; i += gridDim.x * IX_BLOCK) {
         const float *p = points + (size_t)i * q.stride;
         const int b = q.batch_col ? (int)p[0] : q.batch_index;
@@ -245,6 +248,7 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_mark_points(const float *__restri
             if (cz < L.Z && cy < L.Y && cx < L.X) {
                 const int w = lv_word(L, b, cz, cy >> 3, cx >> 3), bit = ((cy & 7) << 3) | (cx & 7);
                 atomicOr(&L.bits[w], 1ull << bit);
+                chunk_flag[w / IX_BLOCK] = 1;             // (many points store the same 1: benign)
                 cell = w * 64 + bit;
             }
         }
@@ -252,13 +256,15 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_mark_points(const float *__restri
     }
 }
 
-__global__ __launch_bounds__(IX_BLOCK) void ix_mark_coords(const int *__restrict__ coords, int n, Lv L, int *__restrict__ pcell) {
+__global__ __launch_bounds__(IX_BLOCK) void ix_mark_coords(const int *__restrict__ coords, int n, Lv L, int *__restrict__ pcell,
+                                                           int *__restrict__ chunk_flag) {
     for (int i = blockIdx.x * IX_BLOCK + threadIdx.x; i < n; i += gridDim.x * IX_BLOCK) {
         const int4 c = reinterpret_cast<const int4 *>(coords)[i];
         int cell = -1;
         if (c.x >= 0 && c.x < L.B && (unsigned)c.y < (unsigned)L.Z && (unsigned)c.z < (unsigned)L.Y && (unsigned)c.w < (unsigned)L.X) {
             const int w = lv_word(L, c.x, c.y, c.z >> 3, c.w >> 3), bit = ((c.z & 7) << 3) | (c.w & 7);
             atomicOr(&L.bits[w], 1ull << bit);
+            chunk_flag[w / IX_BLOCK] = 1;
             cell = w * 64 + bit;
         }
         pcell[i] = cell;
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_mark_coords(const int *__restrict
 // points' atomics have just written, not by the tickets.
 #define IX_CPB 8
 static_assert(IX_CPB <= 64, "ix_count's chunk sums are stored by threads 0 .. IX_CPB-1, which must all be in wave 0 (ix_arrive's contract)");
-__global__ __launch_bounds__(IX_BLOCK) void ix_count(Lv L, IxWs ws, int nchunks) {
+__global__ __launch_bounds__(IX_BLOCK) void ix_count(Lv L, IxWs ws, int nchunks, const int *__restrict__ chunk_flag) {
     __shared__ int lds4[IX_BLOCK / 64];
     __shared__ int part[IX_CPB][2];
     __shared__ int flag;
@@ -281,7 +287,11 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_count(Lv L, IxWs ws, int nchunks)
     for (int jj = 0; jj < IX_CPB / 2; ++jj) {
         const int w = (blockIdx.x * IX_CPB + 2 * jj) * IX_BLOCK + 2 * threadIdx.x;
         int pc = 0;
-        if (w + 1 < L.words) {
+        // level-0 builders: a chunk no point marked is known to be empty (wave-uniform: waves 0-1 / 2-3 share a chunk) — of the voxel
+        // level's 5 664 chunks of a Waymo frame some 10 % hold a site
+        const int chunk_ = blockIdx.x * IX_CPB + 2 * jj + (wave >> 1);
+        if (chunk_flag && chunk_ < nchunks && !chunk_flag[chunk_]) {
+        } else if (w + 1 < L.words) {
             const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(L.bits + w);
             pc = __popcll(v.x) + __popcll(v.y);
         } else if (w < L.words) pc = __popcll(L.bits[w]);
@@ -496,12 +506,19 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_merge_sum(MergeSrc S, Lv Out, flo
 
 // ------------------------------------------------------------------ ranks -> class-sorted rows
 // base[] of every word, cell of every rank, first rank of every sample
-__global__ __launch_bounds__(IX_BLOCK) void ix_rank(Lv L, IxWs ws, int nchunks) {
+__global__ __launch_bounds__(IX_BLOCK) void ix_rank(Lv L, IxWs ws, int nchunks, const int *__restrict__ chunk_flag) {
     __shared__ int lds4[IX_BLOCK / 64];
     // a workgroup walks several 256-word chunks (round 4): the voxel level of a Waymo grid has 5 664 chunks of which ~10 % hold a site,
     // and under four frames in flight a kernel pays for every workgroup it asks the dispatcher for, not for the work inside
     for (int chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const int w = chunk * IX_BLOCK + threadIdx.x;
+        if (chunk_flag && !chunk_flag[chunk]) {      // (uniform) an empty chunk: no site to number, and base[] of an empty word is never used
+            const int per_sample = L.words / L.B;    // ... except that a sample may START here
+            if (w < L.words)
+                for (int b = 0; b < L.B; ++b)
+                    if (w == b * per_sample) ws.sstart[b] = ws.chunk_sums[chunk];
+            continue;
+        }
         unsigned long long v = w < L.words ? L.bits[w] : 0ull;
         int tot;
         int r = ws.chunk_sums[chunk] + ix_block_scan(__popcll(v), lds4, &tot);
@@ -813,9 +830,9 @@ __global__ __launch_bounds__(IX_BLOCK) void ix_rows_of_cells(int n, Lv L, IxWs w
 static int ix_words_grid(const Lv &L) { return aq3d_div_up(L.words, IX_BLOCK); }
 
 // rank / class / scatter of a level whose bitmap and chunk sums are complete
-static void ix_number_rows(const Lv &L, const IxWs &ws, hipStream_t stream) {
+static void ix_number_rows(const Lv &L, const IxWs &ws, hipStream_t stream, const int *chunk_flag = nullptr) {
     const int rank_chunks = ix_words_grid(L);
-    hipLaunchKernelGGL(ix_rank, dim3(rank_chunks < 512 ? rank_chunks : 512), dim3(IX_BLOCK), 0, stream, L, ws, rank_chunks);
+    hipLaunchKernelGGL(ix_rank, dim3(rank_chunks < 512 ? rank_chunks : 512), dim3(IX_BLOCK), 0, stream, L, ws, rank_chunks, chunk_flag);
     if (!L.sorted) {
         if (L.B > 1) hipLaunchKernelGGL(ix_sample_max, dim3(1), dim3(64), 0, stream, L, ws);
         return;
@@ -855,11 +872,11 @@ extern "C" int aq3d_level_from_points(const float *points, int32_t n_points, con
         aq3d_set_error("aq3d_level_from_points: workspace %zu < %zu bytes", workspace_bytes, aq3d_index_workspace_bytes(L.cap, L.words, n_points));
         return AQ3D_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(ix_clear_prev, dim3(128), dim3(IX_BLOCK), 0, stream, L);       // precondition (aq3d.h): bits / coords / count / total consistent, e.g. all zero
+    hipLaunchKernelGGL(ix_clear_prev, dim3(128), dim3(IX_BLOCK), 0, stream, L, ws.chunk_flag, ix_words_grid(L));       // precondition (aq3d.h): bits / coords / count / total consistent, e.g. all zero
     if (n_points > 0)
-        hipLaunchKernelGGL(ix_mark_points, dim3(aq3d_grid(n_points, IX_BLOCK)), dim3(IX_BLOCK), 0, stream, points, n_points, q, L, ws.pcell);
-    hipLaunchKernelGGL(ix_count, dim3(aq3d_div_up(ix_words_grid(L), IX_CPB)), dim3(IX_BLOCK), 0, stream, L, ws, ix_words_grid(L));
-    ix_number_rows(L, ws, stream);
+        hipLaunchKernelGGL(ix_mark_points, dim3(aq3d_grid(n_points, IX_BLOCK)), dim3(IX_BLOCK), 0, stream, points, n_points, q, L, ws.pcell, ws.chunk_flag);
+    hipLaunchKernelGGL(ix_count, dim3(aq3d_div_up(ix_words_grid(L), IX_CPB)), dim3(IX_BLOCK), 0, stream, L, ws, ix_words_grid(L), (const int *)ws.chunk_flag);
+    ix_number_rows(L, ws, stream, ws.chunk_flag);
     if (n_points > 0)
         hipLaunchKernelGGL(ix_link, dim3(aq3d_grid(n_points, IX_BLOCK)), dim3(IX_BLOCK), 0, stream, n_points, L, ws);
     hipLaunchKernelGGL(ix_voxel_features, dim3(aq3d_grid(L.cap, IX_BLOCK)), dim3(IX_BLOCK), 0, stream, points, q, cfg->num_features,
@@ -880,10 +897,10 @@ extern "C" int aq3d_level_from_coords(const int32_t *coords_in, int32_t n, const
         aq3d_set_error("aq3d_level_from_coords: workspace %zu < %zu bytes", workspace_bytes, aq3d_index_workspace_bytes(L.cap, L.words, n));
         return AQ3D_ERR_WORKSPACE;
     }
-    hipLaunchKernelGGL(ix_clear_prev, dim3(128), dim3(IX_BLOCK), 0, stream, L);       // precondition (aq3d.h): bits / coords / count / total consistent, e.g. all zero
-    if (n > 0) hipLaunchKernelGGL(ix_mark_coords, dim3(aq3d_grid(n, IX_BLOCK)), dim3(IX_BLOCK), 0, stream, coords_in, n, L, ws.pcell);
-    hipLaunchKernelGGL(ix_count, dim3(aq3d_div_up(ix_words_grid(L), IX_CPB)), dim3(IX_BLOCK), 0, stream, L, ws, ix_words_grid(L));
-    ix_number_rows(L, ws, stream);
+    hipLaunchKernelGGL(ix_clear_prev, dim3(128), dim3(IX_BLOCK), 0, stream, L, ws.chunk_flag, ix_words_grid(L));       // precondition (aq3d.h): bits / coords / count / total consistent, e.g. all zero
+    if (n > 0) hipLaunchKernelGGL(ix_mark_coords, dim3(aq3d_grid(n, IX_BLOCK)), dim3(IX_BLOCK), 0, stream, coords_in, n, L, ws.pcell, ws.chunk_flag);
+    hipLaunchKernelGGL(ix_count, dim3(aq3d_div_up(ix_words_grid(L), IX_CPB)), dim3(IX_BLOCK), 0, stream, L, ws, ix_words_grid(L), (const int *)ws.chunk_flag);
+    ix_number_rows(L, ws, stream, ws.chunk_flag);
     if (n > 0) hipLaunchKernelGGL(ix_rows_of_cells, dim3(aq3d_grid(n, IX_BLOCK)), dim3(IX_BLOCK), 0, stream, n, L, ws, row_of_input);
     AQ3D_CHECK_LAUNCH("aq3d_level_from_coords");
     return AQ3D_OK;
@@ -955,7 +972,7 @@ extern "C" int aq3d_level_merge(const aq3d_level *const *levels, const int32_t *
         return AQ3D_ERR_WORKSPACE;
     }
     hipLaunchKernelGGL(ix_merge_bits, dim3(aq3d_div_up(Out.words, IX_BLOCK / 64)), dim3(IX_BLOCK), 0, stream, S, Out);
-    hipLaunchKernelGGL(ix_count, dim3(aq3d_div_up(ix_words_grid(Out), IX_CPB)), dim3(IX_BLOCK), 0, stream, Out, ws, ix_words_grid(Out));
+    hipLaunchKernelGGL(ix_count, dim3(aq3d_div_up(ix_words_grid(Out), IX_CPB)), dim3(IX_BLOCK), 0, stream, Out, ws, ix_words_grid(Out), (const int *)nullptr);
     ix_number_rows(Out, ws, stream);
     AQ3D_CHECK_LAUNCH("aq3d_level_merge");
     return AQ3D_OK;
