@@ -48,3 +48,19 @@ def test_eval_loop_writes_the_reference_result_records(dev, tmp_path):
     with torch.no_grad():
         pred, _ = model(b)
     np.testing.assert_array_equal(recs[1]["score"], pred[0]["pred_scores"].cpu().numpy())
+
+
+def test_eval_loop_with_batches(dev, tmp_path):
+    """tools/test.py --batch_size 2: the fp32 model's records equal the frame-by-frame ones (frames are independent); three frames in
+    batches of two (2 + 1)."""
+    ev = _load_eval()
+    cfg = small_cfg("waymo")
+    ds, model = build_model(cfg, n_points=9000, n_voxels=2500, n_frames=3)
+    model.cuda()
+    r1, a1 = ev.eval_one_epoch(cfg, argparse.Namespace(infer_time=False), model, ds, [0, 1, 2], logging.getLogger("t"), str(tmp_path / "a"), dev)
+    r2, a2 = ev.eval_one_epoch(cfg, argparse.Namespace(infer_time=False, batch_size=2), model, ds, [0, 1, 2], logging.getLogger("t"), str(tmp_path / "b"), dev)
+    assert len(a1) == len(a2) == 3 and model.max_batch_size == 2
+    for x, y in zip(a1, a2):
+        assert x["frame_id"] == y["frame_id"]
+        np.testing.assert_array_equal(x["score"], y["score"])
+        np.testing.assert_array_equal(x["boxes_lidar"], y["boxes_lidar"])

@@ -67,11 +67,15 @@ def eval_one_epoch(cfg, args, model, dataset, indices, logger, result_dir, devic
     class_names = dataset.class_names
     det_annos = []
     meter = AverageMeter()
-    start_iter = int(len(indices) * 0.1) if args.infer_time else 0
+    start_iter = int(len(indices) * 0.1 / max(1, int(getattr(args, "batch_size", 1) or 1))) if args.infer_time else 0
     model.eval()
     t_epoch = time.time()
-    for it, idx in enumerate(indices):
-        batch_dict = dataset.collate_batch([dataset[idx]])
+    bs = max(1, int(getattr(args, "batch_size", 1) or 1))        # tools/test.py --batch_size: frames per forward (the model's dynamic
+    if bs > model.max_batch_size:                                 # quantiser statistics are then taken over the batch, as the reference's are)
+        model.max_batch_size = bs
+    groups = [list(indices[i:i + bs]) for i in range(0, len(indices), bs)]
+    for it, grp in enumerate(groups):
+        batch_dict = dataset.collate_batch([dataset[idx] for idx in grp])
         load_data_to_gpu(batch_dict, device)
         if args.infer_time:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -87,8 +91,8 @@ def eval_one_epoch(cfg, args, model, dataset, indices, logger, result_dir, devic
             disp["infer_time"] = "%.2f(%.2f)" % (meter.val, meter.avg)
         statistics_info(cfg, ret_dict, metric, disp)
         det_annos += dataset.generate_prediction_dicts(batch_dict, pred_dicts, class_names)
-        if rank == 0 and (it % max(1, len(indices) // 10) == 0):
-            logger.info("eval %d/%d %s" % (it + 1, len(indices), disp))
+        if rank == 0 and (it % max(1, len(groups) // 10) == 0):
+            logger.info("eval %d/%d %s" % (it + 1, len(groups), disp))
     sec_per_example = (time.time() - t_epoch) / max(1, len(indices))
     logger.info("Generate label finished(sec_per_example: %.4f second)." % sec_per_example)
     if world > 1:       # merge_results_dist (common_utils.py:229-250): rank files + barrier, interleaved back into frame order
@@ -137,6 +141,7 @@ def parse_config(argv=None):
     ap.add_argument("--synthetic", type=int, default=8, help="number of seeded synthetic frames when --frames is not given")
     ap.add_argument("--points", type=int, default=150000)
     ap.add_argument("--voxels", type=int, default=30000)
+    ap.add_argument("--batch_size", type=int, default=1, help="frames per forward (tools/test.py:25)")
     ap.add_argument("--quant", default="sq", choices=["sq", "plain", "none"])
     ap.add_argument("--w_bits", type=int, default=8)
     ap.add_argument("--act_bits", type=int, default=8)
