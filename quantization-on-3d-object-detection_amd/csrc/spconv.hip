@@ -612,11 +612,12 @@ __global__ __launch_bounds__(256) void spconv_small_kernel(SpconvGroup grp, int 
 // weights of a kernel offset are wave-uniform scalar operands), fp32 fma chain in (offset, channel) order — the same chain
 // as the MFMA kernel and the oracle's per-offset matmul. (16 channels per thread — every input gathered once instead of once per
 // channel quad — measured slower, 46 against 37 us: the kernel is a latency chain and the four quads are its parallelism.)
-// Round 4 tried to turn the six dependent memory rounds into two (gather table through LDS as one coalesced block, all 27 x Cin
-// feature loads in flight, eight channels per thread): 57 us with branches around the loads, 57 us with bounded loads, 224 us with
-// the weights in LDS (512 VGPRs + 2.9 KB of scratch) against this kernel's 34 us. What the variants had in common: time followed the
-// per-thread length of the (scalar weight load -> fma) chain, 540 operands here, 1080 there — the chain, not the gathers, is the
-// floor of a plain-VALU formulation (4dc3b90 .. this commit's parent hold the code).
+// Round 4 first tried to turn the six dependent memory rounds into two while still multiplying all 27 offsets (gather table through
+// LDS as one coalesced block, all 27 x Cin feature loads in flight, eight channels per thread): 57 us with branches around the loads,
+// 57 us with bounded loads, 224 us with the weights in LDS (512 VGPRs + 2.9 KB of scratch) against this kernel's 34 us — time followed
+// the per-thread length of the (scalar weight load -> fma) chain, 540 operands here, 1080 there. What worked is further down
+// (spconv_stem_pairs_kernel): not multiplying the ~24 of 27 offsets a voxel does not have. This kernel stays for other kernel volumes
+// and channel counts.
 template <int CIN>
 __global__ __launch_bounds__(256) void spconv_stem_kernel(SpconvArgs a, int cout) {
     int n = *a.count_out;
@@ -693,6 +694,130 @@ __global__ __launch_bounds__(256) void spconv_stem_kernel(SpconvArgs a, int cout
     }
 }
 
+// Round 4, the stem for the 3 x 3 x 3 / 16-output-channel case: work that follows the (row, offset) PAIRS that exist. A LiDAR voxel
+// has ~3 of its 27 neighbours; the kernel above multiplies all 27 (zeros for the missing ones) and gathers every input four times
+// (once per channel quad), and its time follows the per-thread chain of 540 scalar-operand fmas. Here a thread owns one output row
+// and ALL 16 output channels: the 256 x 27 table entries of the workgroup arrive as one coalesced block in LDS, every thread compacts
+// its own 27 entries in place to the (offset, source row) pairs it has, then loops over those — one 5-float gather, 80 fmas with the
+// weights of that offset read from LDS — in ascending offset order. The sums are the chains of the kernel above with the +0 terms of
+// the missing offsets left out: identical bits.
+template <int CIN>
+__global__ __launch_bounds__(256) void spconv_stem_pairs_kernel(SpconvArgs a) {
+    // (measured, rocprof averages at 30 000 rows: 256 rows per workgroup and one pair per round 15.6 us; 128 rows 16.6; 2 / 4 pairs'
+    // gathers in flight per round 17.6 / 19.6 — the gathers are not what the loop waits for)
+    constexpr int KV = 27, CO = 16, WS = 20, NT = 256, G = 1;   // WS: floats per (offset, channel) weight row in LDS (16 + 4 pad); G: pairs in flight
+    __shared__ int s_nbr[NT * KV];
+    __shared__ __attribute__((aligned(16))) float s_w[KV * CIN * WS];
+    int n = *a.count_out;
+    if (n > a.cap_out) n = a.cap_out;
+    const int row0 = blockIdx.x * NT;
+    if (row0 >= n) return;                                   // (uniform) buffers are sized for the capacity, not the frame
+    const int row = row0 + threadIdx.x;
+    const float *x = static_cast<const float *>(a.feats_in);
+    const float *w = static_cast<const float *>(a.weight);        // [kvol][16][CIN]
+    {
+        const int valid = (n - row0 < NT ? n - row0 : NT) * KV;
+        const int *src = a.nbr + (size_t)row0 * KV;
+#pragma unroll
+        for (int i = 0; i < KV; ++i) {
+            const int e = i * NT + threadIdx.x;
+            s_nbr[e] = e < valid ? src[e] : -1;
+        }
+    }
+    for (int i = threadIdx.x; i < KV * CIN * CO; i += NT) {        // s_w[(u * CIN + c) * WS + o] <- w[u][o][c]
+        const int o = i % CO, c = (i / CO) % CIN, u = i / (CO * CIN);
+        s_w[(u * CIN + c) * WS + o] = w[((size_t)u * CO + o) * CIN + c];
+    }
+    __syncthreads();
+    // in-place compaction of the thread's own 27 entries: (offset << 26) | source row for the neighbours that exist
+    int *mine = s_nbr + threadIdx.x * KV;                         // stride 27 words: conflict-free
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < KV; ++u) {
+        const int sr = mine[u];
+        if (sr >= 0) mine[cnt++] = (u << 26) | sr;
+    }
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, 0x7ffffff0, 0x00020000);
+    float acc[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[o] = 0.f;
+    // G pairs per round: their G x CIN gathers are in flight together (bounded loads: a slot past the thread's last pair is an
+    // out-of-range offset = zeros and adds +0 to the chain), then G x 16 x CIN fmas in ascending offset order
+    for (int j0 = 0; j0 < cnt; j0 += G) {
+        int u[G];
+        float xv[G][CIN];
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            const bool live = j0 + q < cnt;
+            const int p = live ? mine[j0 + q] : 0;
+            u[q] = (int)((unsigned)p >> 26);
+            const int sr = p & 0x03ffffff;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+                xv[q][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc_x, live ? (unsigned)((sr * CIN + c) * 4) : 0xfffffff0u, 0, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+            float t[CO];
+#pragma unroll
+            for (int o = 0; o < CO; ++o) t[o] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) {
+                const float *wr = s_w + (u[q] * CIN + c) * WS;
+#pragma unroll
+                for (int o4 = 0; o4 < CO; o4 += 4) {
+                    const float4 wv = *reinterpret_cast<const float4 *>(wr + o4);
+                    t[o4 + 0] = __fmaf_rn(xv[q][c], wv.x, t[o4 + 0]);
+                    t[o4 + 1] = __fmaf_rn(xv[q][c], wv.y, t[o4 + 1]);
+                    t[o4 + 2] = __fmaf_rn(xv[q][c], wv.z, t[o4 + 2]);
+                    t[o4 + 3] = __fmaf_rn(xv[q][c], wv.w, t[o4 + 3]);
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < CO; ++o) acc[o] = __fadd_rn(acc[o], t[o]);
+        }
+    }
+    float mx[CO];
+#pragma unroll
+    for (int o = 0; o < CO; ++o) mx[o] = 0.f;
+    if (row < n) {
+        float out[CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            float v = acc[o];
+            if (a.bias) v = __fadd_rn(v, a.bias[o]);
+            if (a.post_scale) v = __fadd_rn(__fmul_rn(v, a.post_scale[o]), a.post_shift[o]);
+            if (a.residual) v = __fadd_rn(v, a.residual[(size_t)row * CO + o]);
+            if (a.relu) v = fmaxf(v, 0.f);
+            out[o] = v;
+            if (a.next_codes) {       // static PTQ: the consumer's quantiser (identity code layout)
+                float q = rintf(__fmul_rn(v, a.next_scale[o]));
+                q = fminf(fmaxf(q, -a.next_qmax - 1.f), a.next_qmax);
+                a.next_codes[(size_t)row * CO + o] = (int8_t)(int)q;
+            }
+            mx[o] = fabsf(v);
+        }
+        float4 *dst = reinterpret_cast<float4 *>(a.feats_out + (size_t)row * CO);
+#pragma unroll
+        for (int o = 0; o < CO; o += 4) dst[o / 4] = make_float4(out[o], out[o + 1], out[o + 2], out[o + 3]);
+    }
+    if (a.absmax_out) {
+        __shared__ float red[NT / 64][CO];
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            const float m = aq3d_wave_max(mx[o]);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][o] = m;
+        }
+        __syncthreads();
+        if (threadIdx.x < CO) {
+            float m = red[0][threadIdx.x];
+#pragma unroll
+            for (int q = 1; q < NT / 64; ++q) m = fmaxf(m, red[q][threadIdx.x]);
+            if (m > a.absmax_out[threadIdx.x]) aq3d_atomic_max_pos(&a.absmax_out[threadIdx.x], m);
+        }
+    }
+}
+
 static int spconv_group_impl(const aq3d_spconv_problem *probs, int32_t n, int32_t act_mode, int32_t w_mode, int32_t cap_out,
                              int32_t cap_in, int32_t cin, int32_t cout, int32_t kvol, int32_t flags, const float *next_scale,
                              int8_t *next_codes, float next_qmax, void *stream_);
@@ -754,6 +879,16 @@ static int spconv_group_impl(const aq3d_spconv_problem *probs, int32_t n, int32_
     }
     for (int i = n; i < AQ3D_SPCONV_MAX_GROUP; ++i) grp.p[i] = grp.p[0];
     const SpconvArgs &a = grp.p[0];
+    if (n == 1 && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && cin <= 8 && kvol == 27 && cout == 16 && cap_in < (1 << 26)) {
+        const dim3 grid(aq3d_div_up(cap_out, 256));
+        switch (cin) {
+#define AQ3D_STEMP(C_) case C_: hipLaunchKernelGGL(spconv_stem_pairs_kernel<C_>, grid, dim3(256), 0, stream, a); break;
+            AQ3D_STEMP(1) AQ3D_STEMP(2) AQ3D_STEMP(3) AQ3D_STEMP(4) AQ3D_STEMP(5) AQ3D_STEMP(6) AQ3D_STEMP(7) AQ3D_STEMP(8)
+#undef AQ3D_STEMP
+        }
+        AQ3D_CHECK_LAUNCH("aq3d_spconv(stem pairs)");
+        return AQ3D_OK;
+    }
     if (n == 1 && act_mode == AQ3D_ACT_F32 && w_mode == AQ3D_W_F32 && cin <= 8 && (cout & 3) == 0 && cout <= 64) {
         const dim3 grid(aq3d_div_up(cap_out, 256), cout / 4);
         switch (cin) {
