@@ -446,3 +446,62 @@ def test_library_holds_no_packed_fp32_instructions(tmp_path):
     assert len(seen) == 2, seen
     for k, (vgpr, scratch) in seen.items():
         assert vgpr <= 128 and scratch == 0, (k, vgpr, scratch)
+
+
+def test_pseudo_ap_and_thresholded_box_match():
+    """bench.py's accuracy proxy (round 4): a run against itself scores AP 1.0; a missed confident box costs its share of the recall;
+    a detection on one of the reference's low-scoring boxes is ignored, one on nothing is a false positive; the thresholded view
+    filters BOTH sides by the score."""
+    import bench
+    rng = np.random.default_rng(0)
+    n = 40
+    boxes = np.zeros((n, 7), np.float32)
+    boxes[:, 0] = np.arange(n) * 10.0
+    boxes[:, 3:6] = (4.0, 2.0, 1.5)
+    scores = np.linspace(0.95, 0.12, n).astype(np.float32)
+    labels = np.ones(n, np.int64)
+    ref = (boxes, scores, labels)
+    assert bench._pseudo_ap([(ref, ref)], 0.3) == pytest.approx(1.0)
+    n_gt = int((scores >= 0.3).sum())
+    # drop the three most confident boxes from the detections: recall can reach (n_gt - 3) / n_gt at precision 1
+    det = (boxes[3:], scores[3:], labels[3:])
+    assert bench._pseudo_ap([(ref, det)], 0.3) == pytest.approx((n_gt - 3) / n_gt)
+    # a confident detection where the reference has nothing is a false positive in front of everything: the precision envelope at
+    # every recall level is what the full list reaches, n_gt / (n_gt + 1)
+    fp = np.concatenate([np.array([[5000.0, 0, 0, 4, 2, 1.5, 0]], np.float32), boxes])
+    det2 = (fp, np.concatenate([[0.99], scores]).astype(np.float32), np.concatenate([[1], labels]))
+    ap2 = bench._pseudo_ap([(ref, det2)], 0.3)
+    assert ap2 == pytest.approx(n_gt / (n_gt + 1.0), rel=1e-6)
+    # the same extra detection placed on a LOW-scoring reference box is ignored
+    det3 = (np.concatenate([boxes[-1:], boxes]), np.concatenate([[0.99], scores]).astype(np.float32), np.concatenate([[1], labels]))
+    assert bench._pseudo_ap([(ref, det3)], 0.3) == pytest.approx(1.0)
+    a = bench._agg([(ref, det)], 0.3)
+    assert a["boxes_ref"] == n_gt and a["boxes_det"] == n_gt - 3 and a["precision"] == pytest.approx(1.0)
+    assert a["recall"] == pytest.approx((n_gt - 3) / n_gt)
+
+
+def test_heat_map_calibration_sets_a_layer_wide_threshold():
+    """amdq3d.synthetic.calibrate_heat_map: the hidden hm BatchNorm becomes y = (x - t) / e with t the value `fraction` of the layer's
+    activations exceed and e their mean excess — whatever the scale of the activations."""
+    from amdq3d.synthetic import calibrate_heat_map, hm_hidden_paths, init_synthetic_weights
+    from helpers import small_cfg
+    cfg = small_cfg("waymo")
+    from amdq3d.datasets import SyntheticDataset
+    from amdq3d.detector import build_network
+    ds = SyntheticDataset(cfg.DATA_CONFIG, cfg.CLASS_NAMES, n_frames=1, n_points=2000, n_voxels=600, seed0=4)
+    for scale in (1.0, 37.0):
+        model = build_network(cfg.MODEL, len(cfg.CLASS_NAMES), ds)
+        init_synthetic_weights(model, 4)
+        paths = hm_hidden_paths(model)
+        assert paths == ["dense_head.heads_list.0.hm.0.0"]
+        bn = model.dense_head.heads_list[0].hm[0][1]
+        assert float(bn.running_mean.abs().max()) == 0.0 and float(bn.bias.abs().max()) == 0.0        # identity until calibrated
+        rng = np.random.default_rng(1)
+        x = np.maximum(rng.standard_exponential((5000, bn.num_features)) - 1.0, 0.0) * scale
+        calibrate_heat_map(model, {paths[0]: x}, fraction=0.01, min_count=8)
+        t, e = float(bn.running_mean[0]), float(np.sqrt(float(bn.running_var[0]) + bn.eps))
+        assert float(bn.running_mean.max() - bn.running_mean.min()) == 0.0                 # one threshold for the layer
+        frac = float((x > t).mean())
+        assert 0.009 <= frac <= 0.0101
+        assert e == pytest.approx(float((x[x > t] - t).mean()), rel=1e-3)
+        assert t == pytest.approx(np.quantile(x, 0.99), rel=0.02)
