@@ -92,6 +92,130 @@ extern "C" int aq3d_diag_set_i8_stamps(void *p) { return (int)hipMemcpyToSymbol(
 #define I8_STAMP(var)
 #define I8_ACC(acc, from, to)
 #endif
+// Knock-out build of conv2d_i8_kernel for scratch/i8_knockout.py (-DAQ3D_KO=mask; timing only, results are wrong; the product
+// build compiles none of it). bit 0: s | 1/s not loaded; 1: X loaded for the first step only; 2: W loaded for the first step only;
+// 3: no quantisation arithmetic; 4: one MFMA of eight; 5: no LDS stores of the codes. Every workgroup records where and when it ran.
+#ifdef AQ3D_KO
+#define AQ3D_KO_PLACE 1
+__device__ unsigned long long *g_i8_place;           // [workgroups][4]: XCC id, HW id, start, end (100 MHz wall clock)
+extern "C" int aq3d_diag_set_i8_place(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_i8_place), &p, sizeof(p)); }
+#else
+#define AQ3D_KO 0
+#endif
+#ifndef AQ3D_EXP
+#define AQ3D_EXP 0       // experiment switches of the same diagnostic builds (scratch/i8_knockout.py --exp)
+#endif
+
+// ------------------------------------------------------------------ int8 SmoothQuant conv: epilogue of both kernels
+// A lane holds the 4 consecutive output channels base + 4g .. 4g+3 of pixel column l15 of each of its TI x TJ accumulator tiles;
+// pixw = first pixel of the wave's columns, ep = {out_mul, bias, post_scale, post_shift} of the block's channels (LDS), pm = the
+// workgroup's piece maxima (LDS, zeroed at kernel start when a.pieces_out is set).
+template <int TI, int TJ, int BM, int NTH>
+__device__ __forceinline__ void i8_epilogue(const ConvArgs &a, i32x4 (&acc)[TI][TJ], unsigned int *pm, float (*ep)[BM], int pixw, int oc0,
+                                            int wm, int L) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int g = lane >> 4, l15 = lane & 15;
+    // Order (stamps, scratch/cw_stamps.py --dense: the epilogue was
+    // 28 % of the 128 -> 128 layer): operands from LDS (staged at kernel start), values into registers, the output's piece maxima
+    // (interior: DPP row reduction over the 16 pixel lanes, no LDS shuffles), barrier + flush, and the 16-byte output stores LAST —
+    // nothing waits for them.
+    int pcls[TJ];                           // piece class of this lane's TJ pixels; -1 = interior in merged mode
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        pcls[j] = 0;
+        if (a.pieces_out) {
+            const int p = pixw + j * 16 + l15;
+            const int ho = p / a.Wo, wo = p - ho * a.Wo;
+            pcls[j] = (a.pieces_mode == 1 && ho > 0 && ho < a.Ho - 1 && wo > 0 && wo < a.Wo - 1)
+                          ? -1 : piece_cls(ho, a.Ho) * 4 + piece_cls(wo, a.Wo);
+        }
+    }
+    f32x4 vout[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int ol = wm * (BM / 2) + i * 16 + 4 * g;       // channel inside the workgroup's block
+        const int oc = oc0 + ol;
+        const f32x4 mul = *reinterpret_cast<const f32x4 *>(&ep[0][ol]), b = *reinterpret_cast<const f32x4 *>(&ep[1][ol]);
+        const f32x4 ps = *reinterpret_cast<const f32x4 *>(&ep[2][ol]), pt = *reinterpret_cast<const f32x4 *>(&ep[3][ol]);
+        float mint[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int p = pixw + j * 16 + l15;
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = __fmul_rn((float)acc[i][j][r], mul[r]);
+                if (a.bias) t = __fadd_rn(t, b[r]);
+                if (a.post_scale) t = __fadd_rn(__fmul_rn(t, ps[r]), pt[r]);
+                if (a.relu) t = fmaxf(t, 0.f);
+                v[r] = t;
+            }
+            vout[i][j] = v;
+            if (a.pieces_out && p < L && oc < a.Cout) {
+                if (pcls[j] < 0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mint[r] = fmaxf(mint[r], fabsf(v[r]));      // interior: reduced in registers below
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicMax(&pm[pcls[j] * BM + ol + r], __float_as_uint(fabsf(v[r])));
+                }
+            }
+        }
+        if (a.pieces_out && a.pieces_mode == 1) {
+            // interior pixels (98 % of the image): max over this wave's 16 pixel lanes = one DPP row (lanes 16g .. 16g+15), four
+            // row_shr steps leave it in the row's last lane, then ONE LDS atomic per (wave, channel). Values are >= 0: the zeros
+            // DPP feeds for lanes without a source are neutral.
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float m = mint[r];
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x111, 0xf, 0xf, true)));
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x112, 0xf, 0xf, true)));
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x114, 0xf, 0xf, true)));
+                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x118, 0xf, 0xf, true)));
+                if (l15 == 15 && m > 0.f) atomicMax(&pm[10 * BM + ol + r], __float_as_uint(m));
+            }
+        }
+    }
+    if (a.pieces_out) {
+        __syncthreads();
+        for (int i = tid; i < 16 * BM; i += NTH) {
+            const unsigned int v = pm[i];
+            const int pc = i / BM, oc = oc0 + i % BM;
+            if (v != 0u && oc < a.Cout) {
+                unsigned int *dst = reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc * a.pieces_ld + a.out_coff + oc;
+                // mode 1: the merged interior maximum may land in ANY of the four interior classes — every stride-1 consumer takes
+                // the max over all four — so workgroups spread over them: same-address global atomics serialise in L2 (~50 ns
+                // each: 552 workgroups on one slot row lengthen the kernel's tail by tens of microseconds). Fire-and-forget,
+                // no dependent read.
+                if (a.pieces_mode == 1) {
+                    const int alt[4] = {10, 11, 14, 15};
+                    const int pc2 = pc == 10 ? alt[blockIdx.x & 3] : pc;
+                    unsigned int *dst2 = reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc2 * a.pieces_ld + a.out_coff + oc;
+#if AQ3D_EXP & 1
+                    if (v > *dst2)
+#elif AQ3D_EXP & 2
+                    if (v > __hip_atomic_load(dst2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+#endif
+                    atomicMax(dst2, v);
+                } else if (v > *dst) atomicMax(dst, v);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int oc = oc0 + wm * (BM / 2) + i * 16 + 4 * g;
+        if (oc >= a.Cout) continue;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int p = pixw + j * 16 + l15;
+#if AQ3D_EXP & 4
+            if (p < L) __builtin_nontemporal_store(vout[i][j], reinterpret_cast<f32x4 *>(a.y + (size_t)p * a.out_ld + a.out_coff + oc));
+#else
+            if (p < L) *reinterpret_cast<f32x4 *>(a.y + (size_t)p * a.out_ld + a.out_coff + oc) = vout[i][j];
+#endif
+        }
+    }
+}
 
 // ------------------------------------------------------------------ int8 SmoothQuant conv
 // NWN = wave columns (2: 256 threads, 4: 512 threads). The K loop is a per-step dependency chain (global load -> quantise ->
@@ -133,6 +257,9 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     I8_STAMP(t_start);
 #ifdef AQ3D_STAMPS
     unsigned long long s_load = 0, s_mma = 0, s_store = 0, s_bar = 0;
+#endif
+#ifdef AQ3D_KO_PLACE
+    const unsigned long long ko_t0 = wall_clock64();
 #endif
     const int oc0 = blockIdx.y * BM;
     const int cchunks = a.Cin >> 6;
@@ -201,7 +328,7 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     // K steps are issued strictly in order 0, 1, 2, ...: (tap, kh, kw, channel chunk) advance as counters (two integer divisions by
     // run-time values per step were a visible part of the 380 cycles a wave spent ISSUING a step's loads, scratch/cw_stamps.py)
     int ls_tap = 0, ls_kh = 0, ls_kw = 0, ls_c0 = 0;
-    auto load_step = [&](Stage &st, int) {
+    auto load_step = [&](Stage &st, int step) {
         // K order: channel chunk outermost, the taps of one chunk back to back — the nine taps re-read the same fp32 pixels
         // (shifted by a pixel or a row), so their re-use distance is one step (16 KB per workgroup) instead of Cin/64 steps:
         // with tap-major order the 512-channel head conv fetched its input 8.6x from beyond L2. int32 sums: order-free.
@@ -212,24 +339,34 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
         // (measured round 3: fetching s | 1/s with lanes 0-15 only and handing them to the other three pixel groups of the wave by
         // ds_bpermute — a quarter of the vector-memory bytes of these two loads — is 4-11 % SLOWER: the loads hit L1, the shuffles wait)
         const unsigned col = (unsigned)(tap * a.Cin + c0 + cq * 4) * 4u;
-        st.sr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, col, 0, 0));
-        st.rr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, col, 0, 0));
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const bool ok = (pmask[i] >> tap) & 1u;
-            const unsigned off = ok ? (unsigned)(poff[i] + toff) * 4u : 0xfffffff0u;
-            st.xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0));
+        if (!(AQ3D_KO & 1) || step == 0) {
+            st.sr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_s, col, 0, 0));
+            st.rr = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_r, col, 0, 0));
         }
+        if (!(AQ3D_KO & 2) || step == 0) {
 #pragma unroll
-        for (int i = 0; i < WPT; ++i)
-            st.wreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(wrow_off[i] + tap * a.Cin + c0), 0, 0));
+            for (int i = 0; i < PPT; ++i) {
+                const bool ok = (pmask[i] >> tap) & 1u;
+                const unsigned off = ok ? (unsigned)(poff[i] + toff) * 4u : 0xfffffff0u;
+                st.xr[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0));
+            }
+        }
+        if (!(AQ3D_KO & 4) || step == 0) {
+#pragma unroll
+            for (int i = 0; i < WPT; ++i)
+                st.wreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(wrow_off[i] + tap * a.Cin + c0), 0, 0));
+        }
     };
     auto store_step = [&](auto clamp_c, const Stage &st, int buf) {
         constexpr bool CL = decltype(clamp_c)::value;
 #pragma unroll
-        for (int i = 0; i < PPT; ++i)
-            *reinterpret_cast<int *>(Xbuf(buf) + (pg + PGS * i) * LD + swz(pg + PGS * i, cq >> 2) * 16 + (cq & 3) * 4) =
-                quant_pack4<CL>(st.xr[i], st.sr, st.rr, sx);
+        for (int i = 0; i < PPT; ++i) {
+            int code;
+            if (AQ3D_KO & 8) code = __float_as_int(st.xr[i].x) + __float_as_int(st.xr[i].y) + __float_as_int(st.xr[i].z) + __float_as_int(st.xr[i].w) + __float_as_int(st.sr.x);
+            else code = quant_pack4<CL>(st.xr[i], st.sr, st.rr, sx);
+            if (AQ3D_KO & 32) asm volatile("" ::"v"(code));
+            else *reinterpret_cast<int *>(Xbuf(buf) + (pg + PGS * i) * LD + swz(pg + PGS * i, cq >> 2) * 16 + (cq & 3) * 4) = code;
+        }
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int item = tid + NTH * i;
@@ -255,8 +392,10 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
 #pragma unroll
-            for (int j = 0; j < TJ; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TJ; ++j) {
+                if ((AQ3D_KO & 16) && (i | j)) asm volatile("" ::"v"(af[i]), "v"(bf[j]));
+                else acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
     };
     // The whole K loop exists twice, with and without the clamp of calibrated (static) scales: a wave-uniform branch INSIDE the loop
     // made the register allocator rotate the accumulators through other AGPRs every step (40 v_accvgpr_* per step on top of ~110
@@ -295,102 +434,244 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
     else k_loop(std::false_type{});
     I8_STAMP(t_loop);
 
-    // epilogue: lane holds oc = base + 4g .. 4g+3 for pixel column l15. Order (stamps, scratch/cw_stamps.py --dense: the epilogue was
-    // 28 % of the 128 -> 128 layer): operands from LDS (staged at kernel start), values into registers, the output's piece maxima
-    // (interior: DPP row reduction over the 16 pixel lanes, no LDS shuffles), barrier + flush, and the 16-byte output stores LAST —
-    // nothing waits for them.
-    int pcls[TJ];                           // piece class of this lane's TJ pixels; -1 = interior in merged mode
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-        pcls[j] = 0;
-        if (a.pieces_out) {
-            const int p = pix0 + wn * (BN / NWN) + j * 16 + l15;
-            const int ho = p / a.Wo, wo = p - ho * a.Wo;
-            pcls[j] = (a.pieces_mode == 1 && ho > 0 && ho < a.Ho - 1 && wo > 0 && wo < a.Wo - 1)
-                          ? -1 : piece_cls(ho, a.Ho) * 4 + piece_cls(wo, a.Wo);
-        }
-    }
-    f32x4 vout[TI][TJ];
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int ol = wm * (BM / 2) + i * 16 + 4 * g;       // channel inside the workgroup's block
-        const int oc = oc0 + ol;
-        const f32x4 mul = *reinterpret_cast<const f32x4 *>(&ep[0][ol]), b = *reinterpret_cast<const f32x4 *>(&ep[1][ol]);
-        const f32x4 ps = *reinterpret_cast<const f32x4 *>(&ep[2][ol]), pt = *reinterpret_cast<const f32x4 *>(&ep[3][ol]);
-        float mint[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int p = pix0 + wn * (BN / NWN) + j * 16 + l15;
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = __fmul_rn((float)acc[i][j][r], mul[r]);
-                if (a.bias) t = __fadd_rn(t, b[r]);
-                if (a.post_scale) t = __fadd_rn(__fmul_rn(t, ps[r]), pt[r]);
-                if (a.relu) t = fmaxf(t, 0.f);
-                v[r] = t;
-            }
-            vout[i][j] = v;
-            if (a.pieces_out && p < L && oc < a.Cout) {
-                if (pcls[j] < 0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mint[r] = fmaxf(mint[r], fabsf(v[r]));      // interior: reduced in registers below
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicMax(&pm[pcls[j] * BM + ol + r], __float_as_uint(fabsf(v[r])));
-                }
-            }
-        }
-        if (a.pieces_out && a.pieces_mode == 1) {
-            // interior pixels (98 % of the image): max over this wave's 16 pixel lanes = one DPP row (lanes 16g .. 16g+15), four
-            // row_shr steps leave it in the row's last lane, then ONE LDS atomic per (wave, channel). Values are >= 0: the zeros
-            // DPP feeds for lanes without a source are neutral.
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float m = mint[r];
-                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x111, 0xf, 0xf, true)));
-                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x112, 0xf, 0xf, true)));
-                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x114, 0xf, 0xf, true)));
-                m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x118, 0xf, 0xf, true)));
-                if (l15 == 15 && m > 0.f) atomicMax(&pm[10 * BM + ol + r], __float_as_uint(m));
-            }
-        }
-    }
-    if (a.pieces_out) {
-        __syncthreads();
-        for (int i = tid; i < 16 * BM; i += NTH) {
-            const unsigned int v = pm[i];
-            const int pc = i / BM, oc = oc0 + i % BM;
-            if (v != 0u && oc < a.Cout) {
-                unsigned int *dst = reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc * a.pieces_ld + a.out_coff + oc;
-                // mode 1: the merged interior maximum may land in ANY of the four interior classes — every stride-1 consumer takes
-                // the max over all four — so workgroups spread over them: same-address global atomics serialise in L2 (~50 ns
-                // each: 552 workgroups on one slot row lengthen the kernel's tail by tens of microseconds). Fire-and-forget,
-                // no dependent read.
-                if (a.pieces_mode == 1) {
-                    const int alt[4] = {10, 11, 14, 15};
-                    const int pc2 = pc == 10 ? alt[blockIdx.x & 3] : pc;
-                    atomicMax(reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc2 * a.pieces_ld + a.out_coff + oc, v);
-                } else if (v > *dst) atomicMax(dst, v);
-            }
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int oc = oc0 + wm * (BM / 2) + i * 16 + 4 * g;
-        if (oc >= a.Cout) continue;
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            const int p = pix0 + wn * (BN / NWN) + j * 16 + l15;
-            if (p < L) *reinterpret_cast<f32x4 *>(a.y + (size_t)p * a.out_ld + a.out_coff + oc) = vout[i][j];
-        }
-    }
+    i8_epilogue<TI, TJ, BM, NTH>(a, acc, pm, ep, pix0 + wn * (BN / NWN), oc0, wm, L);
 #ifdef AQ3D_STAMPS
     if (lane == 0 && g_i8_stamps) {
         unsigned long long *o = g_i8_stamps + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (NTH / 64) + wave) * 8;
         const unsigned long long t_end = (unsigned long long)clock64();
         o[0] = t_pro - t_start; o[1] = t_fill_v - t_pro; o[2] = s_load; o[3] = s_mma; o[4] = s_store; o[5] = s_bar;
         o[6] = t_end - t_loop; o[7] = ((unsigned long long)nk << 48) | (t_end - t_start);
+    }
+#endif
+#ifdef AQ3D_KO_PLACE
+    if (tid == 0 && g_i8_place) {
+        unsigned long long *o = g_i8_place + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
+        o[0] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        o[1] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+        o[2] = ko_t0;
+        o[3] = wall_clock64();
+    }
+#endif
+}
+
+// ------------------------------------------------------------------ int8 SmoothQuant conv, 3x3 / stride 1 / pad 1: row-register staging
+// Same tiles, K order, LDS layout, MFMA loop and epilogue as conv2d_i8_kernel; what differs is how a K step's operands reach the
+// quantiser. Knock-out builds of the kernel above (scratch/i8_knockout.py, profiles/r04/i8_knockout.jsonl) showed that neither the
+// quantisation arithmetic nor the MFMAs bound it, but the step's chain global load -> wait -> quantise: with all three load streams of
+// a step (X, s | 1/s, W) knocked out the 128 -> 128 layer took 19.0 instead of 26.5 us, with the arithmetic knocked out 24.5.
+//   * A thread stages PQ = BN / 16 CONSECUTIVE pixels of one image row. The three kw taps of a kernel row (kh) read the same PQ + 2
+//     input pixels shifted by one, so ONE set of PQ + 2 loads serves three K steps (2 instead of PQ loads per step and thread), and it
+//     is issued a whole kernel row — three steps — before its first use: the X latency leaves the per-step chain.
+//   * s | 1/s of all K columns are copied to LDS once per workgroup (2 K floats) and read from there: no global load per step. (Round 2
+//     measured this alone as a loss at Cin >= 256; with the X loads gone from the chain the LDS reads are what remains of it.)
+//   * Pixel p of the tile sits in LDS row rho(p) = (p & ~3) | ((p + (p >> 2)) & 3): the four pixels one ds_write_b32 instruction of a
+//     wave covers are PQ apart and would fall into one (PQ = 4) or two (PQ = 2) of the four 16-bank groups; rho rotates every aligned
+//     group of four rows by its index, which spreads them over all four. Rows move only inside aligned groups of four, which the XOR
+//     swizzle of the chunk position does not see: the B-fragment reads stay conflict-free.
+// Requires ks = 3, stride 1, pad 1 (Ho = H, Wo = W), Wo a multiple of PQ (a thread's pixels never straddle an image row).
+template <int TI, int TJ>
+__global__ __launch_bounds__(256, 3) void conv2d_i8r_kernel(ConvGroup grp) {
+    constexpr int NTH = 256, NWN = 2;
+    const ConvArgs a = grp.p[blockIdx.z];
+    if ((int)blockIdx.y * 32 * TI >= a.Cout) return;
+    constexpr int BM = 32 * TI, BN = 16 * TJ * NWN, PQ = BN / 16, NX = PQ + 2;
+    constexpr int LD = 64;
+    auto swz = [](int row, int chunk) { return chunk ^ ((0x1320 >> (((row >> 2) & 3) * 4)) & 3); };
+    auto rho = [](int p) { return (p & ~3) | ((p + (p >> 2)) & 3); };
+    constexpr int WPT = (BM * 4 + NTH - 1) / NTH;
+    static_assert(BM >= 64 && (PQ == 2 || PQ == 4), "tile shape");
+    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * LD];
+    __shared__ unsigned int pm[16 * BM];
+    __shared__ __attribute__((aligned(16))) float ep[4][BM];
+    extern __shared__ __attribute__((aligned(16))) float sr_lds[];      // s[K] | 1/s[K]
+    auto Wbuf = [&](int b) -> char * { return smem + b * (BM + BN) * LD; };
+    auto Xbuf = [&](int b) -> char * { return smem + b * (BM + BN) * LD + BM * LD; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int L = a.Ho * a.Wo;
+    const int K = a.Cin * 9;
+    const int bx = a.xcd_order ? (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int pix0 = bx * BN;
+    if (pix0 >= L) return;
+#ifdef AQ3D_KO_PLACE
+    const unsigned long long ko_t0 = wall_clock64();
+#endif
+    const int oc0 = blockIdx.y * BM;
+    const int cchunks = a.Cin >> 6;
+    const int nrows = 3 * cchunks;          // staging rows: (channel chunk, kh), three K steps each
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, a.H * a.W * a.in_ld * 4, 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void *)a.w, 0, a.Cout * K, 0x00020000);
+
+    // staging role: thread = (channel quad cq, pixel group pq) -> pixels pix0 + PQ * pq + {0 .. PQ-1} of ONE image row
+    const int cq = tid & 15, pq = tid >> 4;
+    const int p0 = pix0 + PQ * pq;
+    const int ho = p0 / a.Wo, wo = p0 - ho * a.Wo;
+    const bool live = p0 < L;
+    const int xbase = ((ho - 1) * a.W + (wo - 1)) * a.in_ld + cq * 4;      // element offset of input pixel (ho - 1, wo - 1), channel 4 cq
+    const bool left_ok = live && wo > 0, right_ok = live && wo + PQ < a.W;
+    unsigned hmask = 0u;                    // kernel rows inside the image
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) hmask |= (unsigned)(live && (unsigned)(ho - 1 + kh) < (unsigned)a.H) << kh;
+
+    f32x4 xa[NX], xb[NX];                   // the input pixels of the kernel row being quantised / of the next one, in flight
+    i32x4 wreg[WPT];
+    int wrow_off[WPT];
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        const int item = min(tid + NTH * i, BM * 4 - 1);
+        wrow_off[i] = min(oc0 + (item >> 2), a.Cout - 1) * K + (item & 3) * 16;
+    }
+    int lr_kh = 0, lr_c0 = 0;               // kernel row / channel chunk of the next load_row
+    auto load_row = [&](f32x4 (&xr)[NX], bool any) {
+        const bool row_ok = any && ((hmask >> lr_kh) & 1u);
+        const int roff = xbase + lr_kh * a.W * a.in_ld + lr_c0;
+        if (++lr_kh == 3) { lr_kh = 0; lr_c0 += 64; }
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            const bool ok = row_ok && (j == 0 ? left_ok : (j == NX - 1 ? right_ok : true));
+            const unsigned off = ok ? (unsigned)(roff + j * a.in_ld) * 4u : 0xfffffff0u;
+            xr[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, off, 0, 0));
+        }
+    };
+    int lw_tap = 0, lw_c0 = 0;              // tap / channel chunk of the next load_w: K steps run chunk-major like conv2d_i8_kernel's
+    auto load_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i)
+            wreg[i] = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (unsigned)(wrow_off[i] + lw_tap * a.Cin + lw_c0), 0, 0));
+        if (++lw_tap == 9) { lw_tap = 0; lw_c0 += 64; }
+    };
+
+    load_row(xb, true);                     // kernel row 0 of chunk 0
+    load_w();                               // K step 0
+    if (a.pieces_out)
+        for (int i = tid; i < 16 * BM; i += NTH) pm[i] = 0u;
+    for (int i = tid; i < BM; i += NTH) {
+        const int oc = oc0 + i;
+        const bool in = oc < a.Cout;
+        ep[0][i] = in ? a.out_mul[oc] : 0.f;
+        ep[1][i] = (in && a.bias) ? a.bias[oc] : 0.f;
+        ep[2][i] = (in && a.post_scale) ? a.post_scale[oc] : 1.f;
+        ep[3][i] = (in && a.post_scale) ? a.post_shift[oc] : 0.f;
+    }
+    for (int i = tid; i < (K >> 2); i += NTH) {
+        reinterpret_cast<f32x4 *>(sr_lds)[i] = reinterpret_cast<const f32x4 *>(a.s)[i];
+        reinterpret_cast<f32x4 *>(sr_lds + K)[i] = reinterpret_cast<const f32x4 *>(a.rinv)[i];
+    }
+    const float sx = a.scal[0];
+    const bool clamp = a.scal[3] != 0.f;
+
+    // LDS offsets of this thread's code dwords (row rho(pixel), chunk cq >> 2) and of its fragment reads
+    int xst[PQ];
+#pragma unroll
+    for (int i = 0; i < PQ; ++i) {
+        const int row = rho(PQ * pq + i);
+        xst[i] = row * LD + swz(row, cq >> 2) * 16 + (cq & 3) * 4;
+    }
+    int bfo[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int row = rho(wn * (BN / NWN) + j * 16 + l15);
+        bfo[j] = row * LD + swz(row, g) * 16;
+    }
+    int qs_col = cq * 4, qs_tap = 0;        // K column (tap * Cin + c0 + 4 cq) of the next step's scales
+    struct Scales { f32x4 s, r; };
+    auto read_scales = [&]() {
+        Scales v;
+        v.s = *reinterpret_cast<const f32x4 *>(sr_lds + qs_col);
+        v.r = *reinterpret_cast<const f32x4 *>(sr_lds + K + qs_col);
+        qs_col += a.Cin;
+        if (++qs_tap == 9) { qs_tap = 0; qs_col += 64 - 9 * a.Cin; }
+        return v;
+    };
+    auto quant_step = [&](auto clamp_c, auto kw_c, const Scales &sc, int buf) {
+        constexpr bool CL = decltype(clamp_c)::value;
+        constexpr int KW = decltype(kw_c)::value;
+#pragma unroll
+        for (int i = 0; i < PQ; ++i) *reinterpret_cast<int *>(Xbuf(buf) + xst[i]) = quant_pack4<CL>(xa[KW + i], sc.s, sc.r, sx);
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int item = tid + NTH * i;
+            if (BM * 4 % NTH == 0 || item < BM * 4)
+                *reinterpret_cast<i32x4 *>(Wbuf(buf) + (item >> 2) * LD + swz(item >> 2, item & 3) * 16) = wreg[i];
+        }
+    };
+
+    i32x4 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = (i32x4){0, 0, 0, 0};
+    auto mma_step = [&](int buf) {
+        i32x4 af[TI], bf[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+            af[i] = *reinterpret_cast<const i32x4 *>(Wbuf(buf) + (wm * (BM / 2) + i * 16 + l15) * LD + swz(l15, g) * 16);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) bf[j] = *reinterpret_cast<const i32x4 *>(Xbuf(buf) + bfo[j]);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+
+    __syncthreads();                        // s | 1/s (and pm, ep) in LDS
+    // Staging row R = K steps 3R .. 3R+2. Entering it, xb holds its input pixels (issued one row earlier): they move to xa and row
+    // R+1's loads start (beyond the last row: out-of-range offsets — no traffic, no branch). Step q: scales of q from LDS, the MFMAs of
+    // step q-1 on the other buffer, quantise(q) + W(q) into buffer q & 1, W(q+1) issued, barrier. The first row exists twice (without
+    // the leading MFMA step): a conditional inside the loop makes the compiler shuttle the accumulators (see conv2d_i8_kernel).
+    int q = 0;
+    auto row_steps = [&](auto clamp_c, auto first_c, int R) {
+#pragma unroll
+        for (int j = 0; j < NX; ++j) xa[j] = xb[j];
+        load_row(xb, R + 1 < nrows);
+        {
+            const Scales sc = read_scales();
+            __builtin_amdgcn_sched_barrier(0);
+            if (!decltype(first_c)::value) mma_step((q - 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            quant_step(clamp_c, std::integral_constant<int, 0>{}, sc, q & 1);
+            load_w();
+            __syncthreads();
+            ++q;
+        }
+        {
+            const Scales sc = read_scales();
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step((q - 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            quant_step(clamp_c, std::integral_constant<int, 1>{}, sc, q & 1);
+            load_w();
+            __syncthreads();
+            ++q;
+        }
+        {
+            const Scales sc = read_scales();
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step((q - 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            quant_step(clamp_c, std::integral_constant<int, 2>{}, sc, q & 1);
+            load_w();                       // after the last step: a column past this row's K, bounded by the buffer — never stored
+            __syncthreads();
+            ++q;
+        }
+    };
+    auto k_loop = [&](auto clamp_c) {
+        row_steps(clamp_c, std::true_type{}, 0);
+        for (int R = 1; R < nrows; ++R) row_steps(clamp_c, std::false_type{}, R);
+        mma_step((q - 1) & 1);
+    };
+    if (clamp) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
+    i8_epilogue<TI, TJ, BM, NTH>(a, acc, pm, ep, pix0 + wn * (BN / NWN), oc0, wm, L);
+#ifdef AQ3D_KO_PLACE
+    if (tid == 0 && g_i8_place) {
+        unsigned long long *o = g_i8_place + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4;
+        o[0] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        o[1] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        o[2] = ko_t0;
+        o[3] = wall_clock64();
     }
 #endif
 }
@@ -652,7 +933,21 @@ extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n,
     for (int i = 0; i < AQ3D_MAX_GROUP; ++i) grp.p[i].xcd_order = 1;
 #define AQ3D_I8_LAUNCH(TI_, TJ_) \
     hipLaunchKernelGGL((conv2d_i8_kernel<TI_, TJ_, 2>), dim3(aq3d_div_up(aq3d_div_up(L, 32 * TJ_), 8) * 8, ocb, n), dim3(256), 0, stream, grp)
-    if (g->Cout >= 128) {
+    // 3x3 / stride 1 / pad 1 with rows a thread's bn / 16 consecutive pixels cannot straddle: the row-register kernel
+    // (128-pixel tiles keep the per-step kernel: ten pixels per row and thread in two register sets leave one wave per SIMD)
+    const bool rows = !(AQ3D_EXP & 8) && g->ksize == 3 && g->stride == 1 && g->pad == 1 && bn <= 64 && g->Wo % (bn / 16) == 0 && g->Cin <= 256;
+    const size_t sr_bytes = (size_t)2 * 9 * g->Cin * sizeof(float);
+#define AQ3D_I8R_LAUNCH(TI_, TJ_) \
+    hipLaunchKernelGGL((conv2d_i8r_kernel<TI_, TJ_>), dim3(aq3d_div_up(aq3d_div_up(L, 32 * TJ_), 8) * 8, ocb, n), dim3(256), sr_bytes, stream, grp)
+    if (rows) {
+        if (g->Cout >= 128) {
+            if (bn == 64) AQ3D_I8R_LAUNCH(4, 2);
+            else AQ3D_I8R_LAUNCH(4, 1);
+        } else {
+            if (bn == 64) AQ3D_I8R_LAUNCH(2, 2);
+            else AQ3D_I8R_LAUNCH(2, 1);
+        }
+    } else if (g->Cout >= 128) {
         if (bn == 128) AQ3D_I8_LAUNCH(4, 4);
         else if (bn == 64) AQ3D_I8_LAUNCH(4, 2);
         else AQ3D_I8_LAUNCH(4, 1);
@@ -662,6 +957,7 @@ extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n,
         else AQ3D_I8_LAUNCH(2, 1);
     }
 #undef AQ3D_I8_LAUNCH
+#undef AQ3D_I8R_LAUNCH
     AQ3D_CHECK_LAUNCH("aq3d_conv2d_i8");
     return AQ3D_OK;
 }

@@ -48,6 +48,10 @@ CASES_I8 = [
     (128, 128, 70, 45, 1, 0.5, False, True),        # several pixel tiles in both directions, ragged right / bottom edges
     (256, 256, 47, 47, 1, 0.5, True, True),         # a 256-channel tile (8 waves' worth of rows), odd image size
     (128, 200, 23, 37, 2, 0.5, False, True),        # Cout that is no multiple of 64: the rows past Cout are computed, never stored
+    (128, 128, 188, 188, 1, 0.5, False, True),      # the benchmark's BEV layer: 64-pixel tiles, four pixels per thread and image row (row-register kernel)
+    (64, 64, 186, 180, 1, 0.5, True, True),         # 64-pixel tiles, 64 output channels, a tile count that is no multiple of 8
+    (128, 128, 182, 182, 1, 0.5, False, True),      # 64-pixel tiles on a width that is no multiple of 4: the per-step kernel
+    (256, 256, 94, 94, 1, 0.5, False, True),        # 32-pixel tiles, two pixels per thread and row, two output-channel blocks
 ]
 
 
