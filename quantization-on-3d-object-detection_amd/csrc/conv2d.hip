@@ -103,7 +103,7 @@ extern "C" int aq3d_diag_set_i8_place(void *p) { return (int)hipMemcpyToSymbol(H
 #define AQ3D_KO 0
 #endif
 #ifndef AQ3D_EXP
-#define AQ3D_EXP 0       // experiment switches of the same diagnostic builds (scratch/i8_knockout.py --exp)
+#define AQ3D_EXP 0       // A/B switches of diagnostic builds (scratch/ab_build.py): 4 = non-temporal output stores, 8 = no row-register kernel
 #endif
 
 // ------------------------------------------------------------------ int8 SmoothQuant conv: epilogue of both kernels
@@ -190,13 +190,7 @@ __device__ __forceinline__ void i8_epilogue(const ConvArgs &a, i32x4 (&acc)[TI][
                 if (a.pieces_mode == 1) {
                     const int alt[4] = {10, 11, 14, 15};
                     const int pc2 = pc == 10 ? alt[blockIdx.x & 3] : pc;
-                    unsigned int *dst2 = reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc2 * a.pieces_ld + a.out_coff + oc;
-#if AQ3D_EXP & 1
-                    if (v > *dst2)
-#elif AQ3D_EXP & 2
-                    if (v > __hip_atomic_load(dst2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-#endif
-                    atomicMax(dst2, v);
+                    atomicMax(reinterpret_cast<unsigned int *>(a.pieces_out) + (size_t)pc2 * a.pieces_ld + a.out_coff + oc, v);
                 } else if (v > *dst) atomicMax(dst, v);
             }
         }

@@ -47,8 +47,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build-only", action="store_true")
     ap.add_argument("--masks", type=int, nargs="+", default=MASKS)
-    ap.add_argument("--exp", type=int, nargs="+", default=[0], help="AQ3D_EXP switch sets (1 plain-load filter in front of the merged-interior "
-                    "atomics, 2 agent-scope load filter, 4 non-temporal output stores), each built with every mask")
+    ap.add_argument("--exp", type=int, nargs="+", default=[0], help="AQ3D_EXP switch sets (4 non-temporal output stores, 8 no row-register kernel), each built with every mask")
     args = ap.parse_args()
     paths = {}
     for e in args.exp:

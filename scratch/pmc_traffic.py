@@ -3,7 +3,7 @@ FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950: it counts 64 B 
 usage: pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass>  → JSON on stdout (profiles/pmc_traffic.json)."""
 import collections, csv, glob, json, sys
 
-FAMILY = [("conv2d_i8_kernel", "conv2d_i8"), ("conv2d_f16s_kernel", "conv2d_f32"), ("conv2d_f32_kernel", "conv2d_f32"),
+FAMILY = [("conv2d_i8_kernel", "conv2d_i8"), ("conv2d_i8r_kernel", "conv2d_i8"), ("conv2d_f16s_kernel", "conv2d_f32"), ("conv2d_f32_kernel", "conv2d_f32"),
           ("sp_prep_kernel", "quantize_rows"), ("quantize_rows_kernel", "quantize_rows"), ("piece_absmax_kernel", "piece_absmax"),
           ("sq_prep", "sq_prep"), ("sq_scales", "sq_prep"), ("sq_weights", "sq_prep"), ("scatter_dense_kernel", "scatter_dense"),
           ("vox_", "voxelize"), ("ix_", "index")]     # ix_*: level-0 build (bench category "voxelize") + strided levels ("index_levels")
