@@ -916,6 +916,10 @@ extern "C" int aq3d_conv2d_i8_group(const aq3d_conv2d_problem *probs, int32_t n,
     int bn = 128;
     if (aq3d_div_up(L, 128) * ocb * n < 512) bn = 64;
     if (aq3d_div_up(L, 64) * ocb * n < 512) bn = 32;
+    // where 128-pixel tiles would be picked (the head's grouped 64 -> 64 convs) the row-register kernel on 64-pixel tiles moves fewer
+    // bytes per pixel (X 8 + W 4 KB per 64 pixels and step against 16 + 2 + 4 of s | 1/s): family time -2.3 %, frame latency -25 us,
+    // frame rate unchanged (profiles/r04/i8_rows_group64_ab.jsonl)
+    if (bn == 128 && !(AQ3D_EXP & 8) && g->ksize == 3 && g->stride == 1 && g->pad == 1 && g->Wo % 4 == 0 && g->Cin <= 256) bn = 64;
     // (also measured: the per-column scales s | 1/s staged once per workgroup in LDS instead of two global loads per thread and step —
     // 2K floats of dynamic LDS cost more occupancy than the loads: Cin = 256: 50 -> 73 us, Cin = 512: 71 -> 101 us, Cin = 128 unchanged)
     // (measured round 2, W150k: forcing 32-pixel tiles or 8 waves per workgroup on the 188 x 188 layers — more waves per SIMD — is

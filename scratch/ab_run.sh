@@ -5,7 +5,7 @@ OUT=gpurun_out/$1; ARGS=$2; shift 2
 PKG="quantization-on-3d-object-detection_amd"
 cp $PKG/libaq3d.so /tmp/libaq3d_product.so
 : > $OUT
-for rep in 1 2; do
+for rep in 1 2 3; do
   for tag in "$@"; do
     cp scratch/diag/libaq3d_ab_$tag.so $PKG/libaq3d.so
     python3 bench.py --no-cpu-baseline --no-accuracy $ARGS > /tmp/ab.json 2> /tmp/ab.err || { tail -5 /tmp/ab.err; cp /tmp/libaq3d_product.so $PKG/libaq3d.so; exit 1; }
