@@ -477,7 +477,9 @@ __global__ __launch_bounds__(256, 3) void conv2d_i8r_kernel(ConvGroup grp) {
     __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * LD];
     __shared__ unsigned int pm[16 * BM];
     __shared__ __attribute__((aligned(16))) float ep[4][BM];
-    extern __shared__ __attribute__((aligned(16))) float sr_lds[];      // s[K] | 1/s[K]
+    extern __shared__ __attribute__((aligned(16))) f32x4 sr_lds[];      // s[K] | 1/s[K], as quads (indexing by quad keeps the reads ds_read_b128:
+                                                                         // through a float pointer the compiler split them into ds_read2_b32 pairs,
+                                                                         // which are banked mod 32 over 32 lanes — PMC: 20 % conflict cycles)
     auto Wbuf = [&](int b) -> char * { return smem + b * (BM + BN) * LD; };
     auto Xbuf = [&](int b) -> char * { return smem + b * (BM + BN) * LD + BM * LD; };
 
@@ -549,9 +551,10 @@ __global__ __launch_bounds__(256, 3) void conv2d_i8r_kernel(ConvGroup grp) {
         ep[2][i] = (in && a.post_scale) ? a.post_scale[oc] : 1.f;
         ep[3][i] = (in && a.post_scale) ? a.post_shift[oc] : 0.f;
     }
-    for (int i = tid; i < (K >> 2); i += NTH) {
-        reinterpret_cast<f32x4 *>(sr_lds)[i] = reinterpret_cast<const f32x4 *>(a.s)[i];
-        reinterpret_cast<f32x4 *>(sr_lds + K)[i] = reinterpret_cast<const f32x4 *>(a.rinv)[i];
+    const int K4 = K >> 2;
+    for (int i = tid; i < K4; i += NTH) {
+        sr_lds[i] = reinterpret_cast<const f32x4 *>(a.s)[i];
+        sr_lds[K4 + i] = reinterpret_cast<const f32x4 *>(a.rinv)[i];
     }
     const float sx = a.scal[0];
     const bool clamp = a.scal[3] != 0.f;
@@ -569,14 +572,15 @@ __global__ __launch_bounds__(256, 3) void conv2d_i8r_kernel(ConvGroup grp) {
         const int row = rho(wn * (BN / NWN) + j * 16 + l15);
         bfo[j] = row * LD + swz(row, g) * 16;
     }
-    int qs_col = cq * 4, qs_tap = 0;        // K column (tap * Cin + c0 + 4 cq) of the next step's scales
+    int qs_quad = cq, qs_tap = 0;           // quad of K columns (tap * Cin + c0) / 4 + cq of the next step's scales
+    const int cin4 = a.Cin >> 2;
     struct Scales { f32x4 s, r; };
     auto read_scales = [&]() {
         Scales v;
-        v.s = *reinterpret_cast<const f32x4 *>(sr_lds + qs_col);
-        v.r = *reinterpret_cast<const f32x4 *>(sr_lds + K + qs_col);
-        qs_col += a.Cin;
-        if (++qs_tap == 9) { qs_tap = 0; qs_col += 64 - 9 * a.Cin; }
+        v.s = sr_lds[qs_quad];
+        v.r = sr_lds[K4 + qs_quad];
+        qs_quad += cin4;
+        if (++qs_tap == 9) { qs_tap = 0; qs_quad += 16 - 9 * cin4; }
         return v;
     };
     auto quant_step = [&](auto clamp_c, auto kw_c, const Scales &sc, int buf) {

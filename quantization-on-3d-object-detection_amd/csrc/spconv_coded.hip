@@ -163,6 +163,18 @@ __device__ __forceinline__ void cd_stage_epilogue(const SpCodedArgs &a, int ob, 
 
 // One 16-channel x 16-row accumulator tile -> output: lane (l15 = row, g) holds channels 4g .. 4g+3. PL planes, plane 0 least
 // significant of those multiplied (the multiplier carries 256^(3 - PL)). Returns the lane's |y| maxima of its four channels.
+// Knock-out build of spconv_cw_kernel for scratch/cw_knockout.py (-DAQ3D_KO_CW=mask; timing only, results are wrong; the product
+// build compiles none of it). bit 0: weight planes staged for the first unit only; 1: codes gathered for the first unit only;
+// 2: one MFMA group of a unit's NT * PL * KS; 3: no fragment reads from LDS either; 4: no output stores; 5: no gather-table staging
+// (every row sees its first unit's neighbours only). Every workgroup records where and when it ran.
+#ifdef AQ3D_KO_CW
+__device__ unsigned long long *g_cw_place;           // [gridDim.x][4]: XCC id, HW id, start, end (100 MHz wall clock); dead tiles stay 0
+extern "C" int aq3d_diag_set_cw_place(void *p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cw_place), &p, sizeof(p)); }
+#define AQ3D_KO_CW_PLACE 1
+#else
+#define AQ3D_KO_CW 0
+#endif
+
 template <int PL, int CT, int COUT>
 __device__ __forceinline__ f32x4v cd_emit_tile(const SpCodedArgs &a, const i32x4v (&acc)[PL], const float *ep, int cl, int ob, int m,
                                                bool live) {
@@ -190,7 +202,8 @@ __device__ __forceinline__ f32x4v cd_emit_tile(const SpCodedArgs &a, const i32x4
         out[r] = v;
         if (a.next_codes) packed |= (cd_static_code(v, ns[r], a.next_qmax) & 0xff) << (8 * r);
     }
-    if (!a.skip_f32) *reinterpret_cast<f32x4v *>(a.feats_out + (size_t)m * COUT + ob + cl) = out;
+    if (AQ3D_KO_CW & 16) asm volatile("" ::"v"(out));
+    else if (!a.skip_f32) *reinterpret_cast<f32x4v *>(a.feats_out + (size_t)m * COUT + ob + cl) = out;
     if (a.next_codes) *reinterpret_cast<int *>(a.next_codes + (size_t)m * COUT + ob + cl) = packed;
 #pragma unroll
     for (int r = 0; r < 4; ++r) out[r] = fabsf(out[r]);
@@ -323,15 +336,23 @@ extern "C" int aq3d_diag_set_stamps(void *p) { return (int)hipMemcpyToSymbol(HIP
 // Cin >= 32. Unit of work = 64 K elements: a 64-channel slice of one kernel offset (Cin >= 64) or TWO kernel offsets x 32
 // channels (Cin = 32). The unit's planes go through LDS (double buffered, XOR-swizzled 64-byte rows), the codes of the wave's
 // row tiles are gathered straight into MFMA B operands: ONE bounded 16-byte buffer load per row and unit.
+// Workgroups per CU. The instantiations with two column blocks per row tile (Cout = 128: ~600 - 1000 live workgroups on the benchmark's
+// levels) are compiled for THREE waves per SIMD (168 VGPRs, 8 spilled dwords outside the unit loop) and, at Cin = 128, stage half-offset
+// units (64 K bytes per row: 41 instead of 65 KB of LDS), so that three workgroups share a CU: -3 % / -5 % of the family's time, -1 % frame
+// latency, frame rate unchanged (profiles/r04/spconv_cw_ub64_ab.jsonl, spconv_cw_three_waves_ab.jsonl). The one-column-block shapes
+// (<= 512 workgroups: everything is resident at two per CU anyway) lose 12 % to the tighter register budget and keep two.
+#ifndef AQ3D_CW128_UB
+#define AQ3D_CW128_UB 64        // A/B (scratch/ab_build.py): 128 = a unit is a whole kernel offset at Cin = 128 (half the barriers, two workgroups per CU)
+#endif
 template <int CIN, int COUT, int CT, int RT, int FD, int PL, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void spconv_cw_kernel(SpCodedArgs a) {
+__global__ __launch_bounds__(64 * NW, (COUT / CT >= 2 && (CIN < 128 || AQ3D_CW128_UB == 64)) ? 3 : 2) void spconv_cw_kernel(SpCodedArgs a) {
     constexpr int NCB = COUT / CT;                      // column blocks: a workgroup computes CT of the COUT output channels
     constexpr int NTH = 64 * NW;                         // NW waves, RT 16-row tiles each
     constexpr int TM = NW * RT * 16;
     constexpr int NT = CT / 16;
     constexpr bool PAIR = CIN == 32;
-    constexpr int UB = CIN >= 128 ? 128 : 64;           // K bytes of a unit per row: at Cin = 128 a unit is one whole kernel offset (a
-    constexpr int KS = UB / 64;                          // code row = one full 128-byte line per gather, half as many barriers)
+    constexpr int UB = CIN >= 128 ? AQ3D_CW128_UB : 64;  // K bytes of a unit per row (64: a 64-channel slice of a kernel offset; 128 at Cin = 128: the
+    constexpr int KS = UB / 64;                          // whole offset, full 128-byte code rows per gather and half the barriers — round 3's form)
     constexpr int NU = PAIR ? 1 : CIN / UB;
     constexpr int ROWS = PL * CT;                        // LDS rows of one unit: (plane, channel), UB bytes each
     constexpr int CPR = UB / 16;                         // 16-byte chunks per row
@@ -357,6 +378,9 @@ __global__ __launch_bounds__(64 * NW, 2) void spconv_cw_kernel(SpCodedArgs a) {
     const int cb = bj % NCB, ob = cb * CT;
     const int row0 = ((bj / NCB) * 8 + ((int)blockIdx.x & 7)) * TM;
     if (row0 >= n) return;
+#ifdef AQ3D_KO_CW_PLACE
+    const unsigned long long ko_t0 = wall_clock64();
+#endif
     CW_STAMP(t_start);
 #ifdef AQ3D_STAMPS
     unsigned long long s_cvt = 0, s_mfma = 0, s_store = 0, s_bar = 0;
@@ -427,8 +451,10 @@ __global__ __launch_bounds__(64 * NW, 2) void spconv_cw_kernel(SpCodedArgs a) {
     // sits on the SOURCE address: slot (r, c) receives chunk swz(r, c) of the row (cdna_hip_programming.md rule 21).
     typedef __attribute__((address_space(1))) const void gptr_t;
     typedef __attribute__((address_space(3))) void lptr_t;
+    bool ko_first = true;                                // knock-out builds: the prologue's calls are the only ones that load
     auto stageW = [&](int b, int k, int h, int k2) {
         if (k >= kvol) return;                           // no next unit (wave-uniform): the idle unit multiplies zero codes
+        if ((AQ3D_KO_CW & 1) && !ko_first) return;
 #pragma unroll
         for (int i = 0; i < NWL; ++i) {
             const int t = tid + NTH * i;
@@ -454,6 +480,7 @@ __global__ __launch_bounds__(64 * NW, 2) void spconv_cw_kernel(SpCodedArgs a) {
         const int rt = q / KS, ks = q % KS;
         const int s = PAIR ? (g < 2 ? src[rt] : src2[rt]) : src[rt];
         const unsigned off = s >= 0 ? (unsigned)s * (unsigned)CIN + (unsigned)(PAIR ? (g & 1) * 16 : h * UB + ks * 64 + 16 * g) : CD_OOB;
+        if ((AQ3D_KO_CW & 2) && !ko_first) return;
         A[rt][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_f, off, 0, 0);
     };
     auto loadA = [&](i32x4v (&A)[RT][KS], int k, int h, int k2) {
@@ -487,6 +514,7 @@ __global__ __launch_bounds__(64 * NW, 2) void spconv_cw_kernel(SpCodedArgs a) {
         const unsigned char *bb = Wb + (size_t)(b * ROWS + l15) * UB;
         auto frag = [&](int j) {
             const int ks = j % KS, pl = (j / KS) % PL, nt = j / (KS * PL);
+            if ((AQ3D_KO_CW & 8) && j > 0) return (i32x4v){j, l15, g, 1};
             return *reinterpret_cast<const i32x4v *>(bb + (pl * CT + nt * 16) * UB + swz(l15, ks * 4 + g) * 16);
         };
         i32x4v fb[FD + 1];
@@ -504,7 +532,10 @@ __global__ __launch_bounds__(64 * NW, 2) void spconv_cw_kernel(SpCodedArgs a) {
             const int ks = j % KS, pl = (j / KS) % PL, nt = j / (KS * PL);
             const i32x4v f = fb[j % (FD + 1)];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) acc[rt][nt][pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f, Acur[rt][ks], acc[rt][nt][pl], 0, 0, 0);
+            for (int rt = 0; rt < RT; ++rt) {
+                if ((AQ3D_KO_CW & 4) && j > 0) asm volatile("" ::"v"(f), "v"(Acur[rt][ks]));
+                else acc[rt][nt][pl] = __builtin_amdgcn_mfma_i32_16x16x64_i8(f, Acur[rt][ks], acc[rt][nt][pl], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -522,6 +553,7 @@ __global__ __launch_bounds__(64 * NW, 2) void spconv_cw_kernel(SpCodedArgs a) {
     const int nunits = PAIR ? (__popc(live) + 1) / 2 : __popc(live) * NU;
     stageW(0, k, h, k2);
     loadA(A0, k, h, k2);
+    ko_first = false;
     __syncthreads();
     CW_STAMP(t_fill);
     for (int u = 0; u < nunits; u += 2) {
@@ -565,6 +597,15 @@ __global__ __launch_bounds__(64 * NW, 2) void spconv_cw_kernel(SpCodedArgs a) {
             if (mx > amax_seen) aq3d_atomic_max_pos(&a.absmax_out[ob + tid], mx);
         }
     }
+#ifdef AQ3D_KO_CW_PLACE
+    if (tid == 0 && g_cw_place) {
+        unsigned long long *o = g_cw_place + (size_t)blockIdx.x * 4;
+        o[0] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        o[1] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+        o[2] = ko_t0;
+        o[3] = wall_clock64();
+    }
+#endif
 #ifdef AQ3D_STAMPS
     if (lane == 0 && g_cw_stamps) {
         unsigned long long *o = g_cw_stamps + ((size_t)blockIdx.x * NW + wave) * 8;
@@ -592,7 +633,7 @@ template <int CIN, int COUT, int CT, int PL, int NW = 4>
 static int launch_cw(const SpCodedArgs &a, hipStream_t stream) {
     constexpr int RT = 2, FD = 4;
     constexpr int TM = NW * 16 * RT;
-    constexpr size_t lds = (size_t)2 * PL * CT * (CIN >= 128 ? 128 : 64) + (size_t)TM * 27 * 4 + (size_t)(5 + NW) * CT * 4 + 64;
+    constexpr size_t lds = (size_t)2 * PL * CT * (CIN >= 128 ? AQ3D_CW128_UB : 64) + (size_t)TM * 27 * 4 + (size_t)(5 + NW) * CT * 4 + 64;
     const int grid = aq3d_div_up(aq3d_div_up(a.cap_out, TM), 8) * 8 * (COUT / CT);
     auto kern = spconv_cw_kernel<CIN, COUT, CT, RT, FD, PL, NW>;
     if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
