@@ -390,7 +390,7 @@ def test_spconv_weight_only_group(dev):
         y = r8["feats_out"][:m].cpu().numpy()
         assert np.abs(y - ref).max() <= 2e-5 * max(1.0, float(np.abs(ref).max()))
     y1 = ops.spconv(fin, recs8[0]["weight"], nbr, count, cout, w_dequant=recs8[0]["w_dequant"], bias=recs8[0]["bias"], relu=True)
-    assert torch.equal(y1, recs8[0]["feats_out"])
+    assert torch.equal(y1[:m], recs8[0]["feats_out"][:m])       # rows past the live count are not written (y1 is an uninitialised buffer)
 
 
 @pytest.mark.parametrize("cin,cout,ksize", [(16, 16, (3, 3, 3)), (16, 32, (3, 3, 3)), (32, 32, (3, 3, 3)), (32, 64, (3, 3, 3)),
