@@ -98,6 +98,32 @@ def test_conv2d_i8_vs_sqconv2d(dev, Cin, Cout, H, W, stride, alpha, use_bias, us
     assert float((y - ref).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("H,W", [(188, 188), (186, 186)])
+def test_conv2d_i8_group_equals_single_launches(dev, H, W):
+    """The head's first convs: five 64 -> 64 SQConv2d problems of one launch class in ONE launch (aq3d_conv2d_i8_group). At 188 x 188 the
+    group runs the row-register kernel on 64-pixel tiles (where the tile rule alone would pick 128-pixel tiles), at 186 x 186 — a width
+    that is no multiple of 4 — the per-step kernel on 128-pixel tiles; every problem must equal its single launch bit for bit."""
+    from amdq3d import ops
+    g_ = torch.Generator().manual_seed(H)
+    Cin = Cout = 64
+    x = (torch.relu(torch.randn(H, W, Cin, generator=g_)) * (torch.rand(Cin, generator=g_) * 3 + 0.1)).to(dev)
+    geom = ops.conv_geom(H, W, Cin, Cout, 3, 1, 1, relu=True)
+    pieces = ops.piece_absmax(x, H, W, Cin)
+    recs, singles = [], []
+    for k in range(5):
+        w = torch.randn(Cout, Cin, 3, 3, generator=g_) / np.sqrt(9 * Cin)
+        wk = ops.conv_weight_to_k(w).to(dev)
+        params = ops.sq_prep(pieces, wk, wk.abs().max(dim=0)[0].contiguous(), geom, 0.5)
+        bias = (torch.randn(Cout, generator=g_) * 0.1).to(dev)
+        ps, pt = (torch.rand(Cout, generator=g_) + 0.5).to(dev), (torch.randn(Cout, generator=g_) * 0.1).to(dev)
+        singles.append(ops.conv2d_i8(x, params, geom, bias=bias, post_scale=ps, post_shift=pt))
+        recs.append(dict(x=x, w=params, g=geom, bias=bias, post_scale=ps, post_shift=pt, y=torch.zeros((H, W, Cout), device=dev)))
+    ops.conv2d_i8_group(ops.conv_problems(recs))
+    for r, y1 in zip(recs, singles):
+        assert torch.equal(r["y"], y1)
+    assert not torch.equal(singles[0], singles[1])
+
+
 CASES_F32 = [
     # Cin, Cout, H, W, ksize, stride, pad
     (64, 64, 24, 20, 3, 1, 1),
