@@ -450,18 +450,22 @@ __global__ __launch_bounds__(128 * NWN) void conv2d_i8_kernel(ConvGroup grp) {
 
 // ------------------------------------------------------------------ int8 SmoothQuant conv, 3x3 / stride 1 / pad 1: row-register staging
 // Same tiles, K order, LDS layout, MFMA loop and epilogue as conv2d_i8_kernel; what differs is how a K step's operands reach the
-// quantiser. Knock-out builds of the kernel above (scratch/i8_knockout.py, profiles/r04/i8_knockout.jsonl) showed that neither the
-// quantisation arithmetic nor the MFMAs bound it, but the step's chain global load -> wait -> quantise: with all three load streams of
-// a step (X, s | 1/s, W) knocked out the 128 -> 128 layer took 19.0 instead of 26.5 us, with the arithmetic knocked out 24.5.
+// quantiser. Knock-out builds of the kernel above (scratch/i8_knockout.py, profiles/r04/i8_knockout.jsonl) put the
+// step's three load streams at 1.7 (X) + 0.75 (s | 1/s) + 1.45 (W) of the 128 -> 128 layer's 26.5 us, roughly additive with the
+// quantisation (2.0) and the MFMAs (3.6): nothing overlaps much at two to three workgroups per CU, so bytes through the vector-memory
+// path are worth removing even though no single stream binds.
 //   * A thread stages PQ = BN / 16 CONSECUTIVE pixels of one image row. The three kw taps of a kernel row (kh) read the same PQ + 2
 //     input pixels shifted by one, so ONE set of PQ + 2 loads serves three K steps (2 instead of PQ loads per step and thread), and it
-//     is issued a whole kernel row — three steps — before its first use: the X latency leaves the per-step chain.
-//   * s | 1/s of all K columns are copied to LDS once per workgroup (2 K floats) and read from there: no global load per step. (Round 2
-//     measured this alone as a loss at Cin >= 256; with the X loads gone from the chain the LDS reads are what remains of it.)
-//   * Pixel p of the tile sits in LDS row rho(p) = (p & ~3) | ((p + (p >> 2)) & 3): the four pixels one ds_write_b32 instruction of a
-//     wave covers are PQ apart and would fall into one (PQ = 4) or two (PQ = 2) of the four 16-bank groups; rho rotates every aligned
-//     group of four rows by its index, which spreads them over all four. Rows move only inside aligned groups of four, which the XOR
-//     swizzle of the chunk position does not see: the B-fragment reads stay conflict-free.
+//     is issued a whole kernel row — three steps — before its first use.
+//   * s | 1/s of all K columns are copied to LDS once per workgroup (2 K floats, read as f32x4 quads: ds_read_b128) — no global load
+//     per step. (Staging them per kernel row instead, 3 KB whatever K, measured slower twice; at Cin = 512 the resident block costs a
+//     workgroup per CU, so that layer keeps the per-step kernel.)
+//   * Pixel p of the tile sits in LDS row rho(p) = (p & ~3) | ((p + (p >> 2)) & 3). ds_write_b32 is served in two groups of 32 lanes
+//     on 32 banks (MI355X_MICROARCH.md, LDS table): a group holds the code dwords of two pixel groups, whose rows are PQ apart — 256
+//     bytes at PQ = 4, the same 16 banks. rho rotates every aligned group of four rows by its index, which puts them 64 bytes apart
+//     (conflict-free at PQ = 4 by the guide's rules; PQ = 2 keeps a 2-way conflict, which a ds_write_b32 absorbs). Rows move only inside
+//     aligned groups of four, which the XOR swizzle of the chunk position does not see: the B-fragment reads stay conflict-free
+//     (PMC: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 1 % / 8 % / 0 % for <4, 2> / <4, 1> / <2, 2>).
 // Requires ks = 3, stride 1, pad 1 (Ho = H, Wo = W), Wo a multiple of PQ (a thread's pixels never straddle an image row).
 template <int TI, int TJ>
 __global__ __launch_bounds__(256, 3) void conv2d_i8r_kernel(ConvGroup grp) {
